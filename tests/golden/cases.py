@@ -1,0 +1,164 @@
+"""Golden-vector case table and deterministic input generation.
+
+Shared by ``make_goldens.py`` (runs only where /root/reference is mounted),
+``tests/test_oracle_golden.py`` (CPU) and ``tests/test_hip_golden.py`` (GPU).
+Inputs are regenerated from the frozen legacy ``numpy.random.RandomState``
+stream (bit-stable across numpy releases) or from a closed-form pattern, so the
+fixtures only store the reference OUTPUTS.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@dataclass(frozen=True)
+class TextCase:
+    name: str
+    n: int            # frames
+    s: int            # query tokens
+    heads: int
+    d: int            # head dim
+    cross: bool       # text cross-attention (L=77) or self-attention
+    mode: str         # plain | pure_outer | fused_outer | pure_inner | fused_inner
+    l: int = 77
+    cc: int = 48      # context width for cross cases
+    t: Optional[float] = None      # given t -> coef [0,t,1] (n must be 3)
+    alpha: float = 3.0
+    beta: float = 3.0
+    seed: int = 0
+
+    @property
+    def c(self) -> int:
+        return self.heads * self.d
+
+
+@dataclass(frozen=True)
+class IPCase:
+    name: str
+    kind: str         # outer_ip | inner_ip | scale_control | scale_control_off
+    is_fused: bool
+    tokens: int       # T image tokens
+    s: int = 24
+    heads: int = 2
+    d: int = 40
+    l: int = 77
+    cc: int = 48
+    t: float = 0.3
+    ip_scale: float = 0.6
+    seed: int = 0
+
+    @property
+    def c(self) -> int:
+        return self.heads * self.d
+
+
+def _text_cases() -> List[TextCase]:
+    cases: List[TextCase] = []
+    sd = 100
+    # N=3, t given, d=40 (SD1.5 level-0 head dim), ragged S
+    for cross in (False, True):
+        for mode in ("pure_outer", "fused_outer", "pure_inner", "fused_inner", "plain"):
+            sd += 1
+            cases.append(TextCase(f"n3_d40_{'x' if cross else 's'}_{mode}", 3, 40, 2, 40, cross, mode,
+                                  t=0.3, seed=sd))
+    # N=7, Beta(3,3) coefficients, d=64 (SDXL head dim), S not a multiple of 32
+    for cross in (False, True):
+        for mode in ("fused_outer", "fused_inner", "plain"):
+            sd += 1
+            cases.append(TextCase(f"n7_d64_{'x' if cross else 's'}_{mode}", 7, 33, 2, 64, cross, mode,
+                                  cc=64, seed=sd))
+    # d=80 / d=160 (SD1.5 deeper levels), one head
+    for d in (80, 160):
+        for mode in ("fused_outer", "fused_inner"):
+            sd += 1
+            cases.append(TextCase(f"n3_d{d}_s_{mode}", 3, 24, 1, d, False, mode, t=0.7, seed=sd))
+    # N=5, Beta(25,25) pure modes on d=64
+    for mode in ("pure_outer", "pure_inner"):
+        sd += 1
+        cases.append(TextCase(f"n5_d64_s_{mode}", 5, 16, 2, 64, False, mode, alpha=25, beta=25, seed=sd))
+    return cases
+
+
+def _ip_cases() -> List[IPCase]:
+    cases: List[IPCase] = []
+    sd = 300
+    for tokens in (4, 16):
+        for kind, fused in (("outer_ip", True), ("outer_ip", False), ("inner_ip", True),
+                            ("scale_control", True), ("scale_control", False),
+                            ("scale_control_off", True)):
+            sd += 1
+            cases.append(IPCase(f"ip{tokens}_{kind}_{'fused' if fused else 'pure'}", kind, fused, tokens, seed=sd))
+    return cases
+
+
+TEXT_CASES: List[TextCase] = _text_cases()
+IP_CASES: List[IPCase] = _ip_cases()
+
+
+# ---------------------------------------------------------------------------
+def randn(rs: np.random.RandomState, *shape, scale: float = 1.0) -> np.ndarray:
+    return (rs.standard_normal(shape) * scale).astype(np.float32)
+
+
+def text_inputs(case: TextCase) -> Dict[str, np.ndarray]:
+    """x ~ N(0,1); weights ~ N(0, 1/fan_in); bias ~ N(0, .01)."""
+    rs = np.random.RandomState(case.seed)
+    c = case.c
+    cc = case.cc if case.cross else c
+    inp = dict(
+        x=randn(rs, case.n, case.s, c),
+        wq=randn(rs, c, c, scale=c ** -0.5),
+        wk=randn(rs, c, cc, scale=cc ** -0.5),
+        wv=randn(rs, c, cc, scale=cc ** -0.5),
+        wo=randn(rs, c, c, scale=c ** -0.5),
+        bo=randn(rs, c, scale=0.01),
+    )
+    if case.cross:
+        inp["ctx"] = randn(rs, case.n, case.l, cc)
+    return inp
+
+
+def ip_inputs(case: IPCase) -> Dict[str, np.ndarray]:
+    rs = np.random.RandomState(case.seed)
+    c, cc = case.c, case.cc
+    return dict(
+        x=randn(rs, 3, case.s, c),
+        text=randn(rs, 3, case.l, cc),
+        ip=randn(rs, 9, 1, case.tokens, cc),
+        wq=randn(rs, c, c, scale=c ** -0.5),
+        wk=randn(rs, c, cc, scale=cc ** -0.5),
+        wv=randn(rs, c, cc, scale=cc ** -0.5),
+        wo=randn(rs, c, c, scale=c ** -0.5),
+        bo=randn(rs, c, scale=0.01),
+        wk_ip=randn(rs, c, cc, scale=cc ** -0.5),
+        wv_ip=randn(rs, c, cc, scale=cc ** -0.5),
+    )
+
+
+def pat(shape, phi: float, s: float) -> np.ndarray:
+    """Closed-form pattern of SURVEY.md App. F: s*sin(0.37*k + phi) over the
+    row-major index k, computed in fp64 and cast to fp32."""
+    k = np.arange(int(np.prod(shape)), dtype=np.float64)
+    return (s * np.sin(0.37 * k + phi)).reshape(shape).astype(np.float32)
+
+
+def kat_inputs(cross: bool) -> Dict[str, np.ndarray]:
+    """SURVEY.md App. F closed-form known-answer case (N=3,S=4,C=8,H=2; L=5,Cc=6)."""
+    n, s, c, l, cc = 3, 4, 8, 5, 6
+    cctx = cc if cross else c
+    inp = dict(x=pat((n, s, c), 1.0, 1.0), wq=pat((c, c), .1, .5), wk=pat((c, cctx), .2, .5),
+               wv=pat((c, cctx), .3, .5), wo=pat((c, c), .4, .5), bo=pat((c,), .5, .1))
+    if cross:
+        inp["ctx"] = pat((n, l, cc), 2.0, 1.0)
+    return inp
+
+
+def load_fixture(name: str) -> Dict[str, np.ndarray]:
+    with np.load(os.path.join(HERE, name)) as z:
+        return {k: z[k] for k in z.files}
