@@ -1,0 +1,28 @@
+"""attention-interpolation-diffusion_amd — MI355X-native (gfx950 / CDNA4) interpolated attention
+for diffusion (AID / PAID): a drop-in for the attention-processor hot path of
+QY-H00/attention-interpolation-diffusion.
+
+The directory name contains hyphens; import the package through the ``aid_amd`` alias module at
+the repository root (``import aid_amd``).
+
+Layout:  csrc/ (HIP kernels + C ABI, built to libaid_hip.so)  ·  _lib.py (ctypes binding)  ·
+ops.py (tensor-level entry points)  ·  processors.py (the reference's AttnProcessor classes)  ·
+interp.py (coefficients, slerp / lerp initialisation)  ·  attn_shim.py (diffusers stand-ins)  ·
+dist.py (frame sharding over RCCL)  ·  loop.py (denoising-loop harness).
+"""
+from .interp import generate_beta_tensor, linear_interpolation, slerp, spherical_interpolation
+from .processors import (HipAttnProcessor, InnerInterpolatedAttnProcessor, InnerInterpolatedIPAttnProcessor,
+                         InterpolatedAttnProcessor, OuterInterpolatedAttnProcessor,
+                         OuterInterpolatedIPAttnProcessor, ScaleControlIPAttnProcessor, activate_aid,
+                         deactivate_aid, load_aid)
+from .attn_shim import AttnShim, AttnStackUNet, IPAdapterShim
+from . import ops, _lib
+
+__all__ = [
+    "generate_beta_tensor", "linear_interpolation", "slerp", "spherical_interpolation",
+    "InterpolatedAttnProcessor", "OuterInterpolatedAttnProcessor", "InnerInterpolatedAttnProcessor",
+    "OuterInterpolatedIPAttnProcessor", "InnerInterpolatedIPAttnProcessor", "ScaleControlIPAttnProcessor",
+    "HipAttnProcessor", "load_aid", "activate_aid", "deactivate_aid",
+    "AttnShim", "AttnStackUNet", "IPAdapterShim", "ops",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,114 @@
+"""ctypes binding of ``libaid_hip.so`` (C ABI declared in ``include/aid_hip.h``).
+
+The shared library is built in-tree (``attention-interpolation-diffusion_amd/libaid_hip.so``) by
+``__graft_entry__.build()`` / ``csrc/Makefile``.  There is NO fallback: if the library is missing
+or a call returns a non-zero code, a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libaid_hip.so")
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+
+AID_ABI_VERSION = 1
+DTYPE_F16, DTYPE_BF16 = 0, 1
+MODE_PLAIN, MODE_INNER, MODE_OUTER = 0, 1, 2
+GEMM_MAX_PROBLEMS = 4
+
+# every symbol include/aid_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "aid_gemm_nt", "aid_attn_fwd", "aid_processor_workspace_bytes", "aid_processor_fwd",
+    "aid_abi_version", "aid_strerror", "aid_last_attn_variant", "aid_device_info",
+)
+
+
+class AidGemmProblem(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("bias", C.c_void_p),
+        ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+        ("batch", C.c_int32), ("_pad", C.c_int32),
+        ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64),
+    ]
+
+
+class AidAttnArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
+        ("coef", C.c_void_p), ("frame_scale", C.c_void_p), ("kv_map", C.c_void_p),
+        ("n_frames", C.c_int32), ("n_kv", C.c_int32),
+        ("s", C.c_int32), ("l", C.c_int32), ("heads", C.c_int32), ("d", C.c_int32),
+        ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldvt", C.c_int32), ("ldo", C.c_int32),
+        ("q_fs", C.c_int64), ("k_fs", C.c_int64), ("vt_fs", C.c_int64), ("o_fs", C.c_int64),
+        ("mode", C.c_int32), ("fused", C.c_int32), ("begin", C.c_int32), ("end", C.c_int32),
+        ("accumulate", C.c_int32), ("dtype", C.c_int32),
+        ("softmax_scale", C.c_float), ("out_scale", C.c_float),
+    ]
+
+
+class AidProcessorArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ctx", C.c_void_p), ("wq", C.c_void_p), ("wk", C.c_void_p),
+        ("wv", C.c_void_p), ("wo", C.c_void_p), ("bo", C.c_void_p), ("y", C.c_void_p),
+        ("coef", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("n_frames", C.c_int32), ("s", C.c_int32), ("l", C.c_int32), ("c", C.c_int32),
+        ("cc", C.c_int32), ("heads", C.c_int32), ("mode", C.c_int32), ("fused", C.c_int32),
+        ("begin", C.c_int32), ("end", C.c_int32), ("dtype", C.c_int32), ("n_ctx", C.c_int32),
+        ("ctx_map", C.c_void_p),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the gfx950 shared library in-tree with hipcc (cross-compiles without a GPU)."""
+    proc = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout[-4000:])
+        print(proc.stderr[-4000:])
+    if proc.returncode != 0:
+        raise RuntimeError("building libaid_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libaid_hip.so; raise if it is absent (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            f"(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC_DIR}`). "
+            "This package has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.aid_abi_version.restype = C.c_int
+    lib.aid_strerror.restype = C.c_char_p
+    lib.aid_strerror.argtypes = [C.c_int]
+    lib.aid_last_attn_variant.restype = C.c_char_p
+    lib.aid_device_info.restype = C.c_int
+    lib.aid_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p]
+    lib.aid_gemm_nt.restype = C.c_int
+    lib.aid_gemm_nt.argtypes = [C.POINTER(AidGemmProblem), C.c_int, C.c_int, C.c_void_p]
+    lib.aid_attn_fwd.restype = C.c_int
+    lib.aid_attn_fwd.argtypes = [C.POINTER(AidAttnArgs), C.c_void_p]
+    lib.aid_processor_workspace_bytes.restype = C.c_size_t
+    lib.aid_processor_workspace_bytes.argtypes = [C.POINTER(AidProcessorArgs)]
+    lib.aid_processor_fwd.restype = C.c_int
+    lib.aid_processor_fwd.argtypes = [C.POINTER(AidProcessorArgs), C.c_void_p]
+    if lib.aid_abi_version() != AID_ABI_VERSION:
+        raise RuntimeError(f"libaid_hip.so ABI version {lib.aid_abi_version()} != expected {AID_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().aid_strerror(code).decode()
+        raise RuntimeError(f"{what} failed with code {code}: {msg}")

@@ -1,0 +1,212 @@
+// extern "C" boundary of libaid_hip.so (see include/aid_hip.h).  Argument checking, workspace
+// carving and launch sequencing only — every byte of arithmetic happens in the gfx950 kernels of
+// aid_gemm.hip / aid_attn.hip.  No allocation, no synchronisation, no exceptions.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "aid_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[256] = "";
+thread_local const char* g_variant = "";
+
+int fail_hip(hipError_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return AID_ERR_LAUNCH;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+int check_problem(const AidGemmProblem& q) {
+    if (!q.a || !q.b || !q.c) return AID_ERR_ARG;
+    if (q.m < 0 || q.n < 0 || q.k <= 0 || q.batch < 1) return AID_ERR_ARG;
+    if (q.k % 8 || q.lda % 8 || q.ldb % 8 || q.ldc % 4) return AID_ERR_SHAPE;
+    if (q.lda < q.k || q.ldb < q.k || q.ldc < round_up(q.n, 4)) return AID_ERR_SHAPE;
+    if (!aligned16(q.a) || !aligned16(q.b) || !aligned16(q.c)) return AID_ERR_SHAPE;
+    if ((q.stride_a % 8) || (q.stride_b % 8) || (q.stride_c % 4)) return AID_ERR_SHAPE;
+    return AID_OK;
+}
+
+struct Carve {
+    size_t q, k, vt, o, total;
+    int lp;
+};
+
+Carve carve(const AidProcessorArgs& a) {
+    Carve c;
+    const size_t es = 2;
+    const int nctx = a.ctx ? a.n_ctx : a.n_frames;
+    const int l = a.ctx ? a.l : a.s;
+    c.lp = round_up(l, 8);
+    size_t off = 0;
+    c.q = off;  off += align_up((size_t)a.n_frames * a.s * a.c * es, 256);
+    c.k = off;  off += align_up((size_t)nctx * l * a.c * es, 256);
+    c.vt = off; off += align_up((size_t)nctx * a.c * c.lp * es, 256);
+    c.o = off;  off += align_up((size_t)a.n_frames * a.s * a.c * es, 256);
+    c.total = off;
+    return c;
+}
+
+int check_processor(const AidProcessorArgs& a) {
+    if (!a.x || !a.wq || !a.wk || !a.wv || !a.wo || !a.y) return AID_ERR_ARG;
+    if (a.dtype != AID_DTYPE_F16 && a.dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (a.n_frames < 1 || a.s < 1 || a.c < 1 || a.heads < 1 || a.c % a.heads) return AID_ERR_ARG;
+    if (a.mode < AID_MODE_PLAIN || a.mode > AID_MODE_OUTER) return AID_ERR_ARG;
+    if (a.mode != AID_MODE_PLAIN && !a.coef) return AID_ERR_ARG;
+    if (!aid::attn_head_dim_supported(a.c / a.heads)) return AID_ERR_SHAPE;
+    if (a.c % 8) return AID_ERR_SHAPE;
+    const int nctx = a.ctx ? a.n_ctx : a.n_frames;
+    if (a.ctx) {
+        if (a.l < 1 || a.cc < 8 || a.cc % 8 || a.n_ctx < 1) return AID_ERR_ARG;
+        if (!a.ctx_map && a.n_ctx != a.n_frames) return AID_ERR_ARG;
+    } else if (a.ctx_map) {
+        return AID_ERR_ARG;
+    }
+    if (a.mode != AID_MODE_PLAIN && (a.begin < 0 || a.begin >= nctx || a.end < 0 || a.end >= nctx)) return AID_ERR_ARG;
+    return AID_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aid_abi_version(void) { return AID_ABI_VERSION; }
+
+const char* aid_strerror(int code) {
+    switch (code) {
+        case AID_OK: return "ok";
+        case AID_ERR_ARG: return "invalid argument (NULL pointer, negative size or inconsistent field)";
+        case AID_ERR_DTYPE: return "unsupported dtype (AID_DTYPE_F16 / AID_DTYPE_BF16 only)";
+        case AID_ERR_SHAPE: return "unsupported shape or alignment (head dim must be 40/64/80/160; see aid_hip.h)";
+        case AID_ERR_WORKSPACE: return "workspace too small or misaligned";
+        case AID_ERR_LAUNCH: return g_err[0] ? g_err : "kernel launch failed";
+        case AID_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown error code";
+    }
+}
+
+const char* aid_last_attn_variant(void) { return g_variant; }
+
+int aid_device_info(int* n_cu, int* clock_khz, char* arch) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return AID_ERR_NO_DEVICE;
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return AID_ERR_NO_DEVICE;
+    if (n_cu) *n_cu = pr.multiProcessorCount;
+    if (clock_khz) *clock_khz = pr.clockRate;
+    if (arch) { strncpy(arch, pr.gcnArchName, 31); arch[31] = 0; }
+    return AID_OK;
+}
+
+int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void* stream) {
+    if (!problems || n_problems < 1 || n_problems > AID_GEMM_MAX_PROBLEMS) return AID_ERR_ARG;
+    if (dtype != AID_DTYPE_F16 && dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    aid::GemmGroup g;
+    memset(&g, 0, sizeof(g));
+    g.n_problems = n_problems;
+    int tiles = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const AidGemmProblem& q = problems[i];
+        int rc = check_problem(q);
+        if (rc != AID_OK) return rc;
+        aid::GemmDesc& d = g.p[i];
+        d.a = q.a; d.b = q.b; d.c = q.c; d.bias = q.bias;
+        d.m = q.m; d.n = q.n; d.k = q.k;
+        d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc;
+        d.stride_a = q.stride_a; d.stride_b = q.stride_b; d.stride_c = q.stride_c;
+        g.tile_start[i] = tiles;
+        tiles += aid::gemm_tiles(q.m, q.n, q.batch);
+    }
+    for (int i = n_problems; i <= AID_GEMM_MAX_PROBLEMS; ++i) g.tile_start[i] = tiles;
+    hipError_t e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AID_OK : fail_hip(e, "aid_gemm_nt");
+}
+
+int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
+    if (!args) return AID_ERR_ARG;
+    const AidAttnArgs& a = *args;
+    if (!a.q || !a.k || !a.vt || !a.out) return AID_ERR_ARG;
+    if (a.dtype != AID_DTYPE_F16 && a.dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (a.mode < AID_MODE_PLAIN || a.mode > AID_MODE_OUTER) return AID_ERR_ARG;
+    if (a.n_frames < 1 || a.n_kv < 1 || a.s < 1 || a.l < 1 || a.heads < 1) return AID_ERR_ARG;
+    if (a.mode != AID_MODE_PLAIN && (!a.coef || a.begin < 0 || a.begin >= a.n_kv || a.end < 0 || a.end >= a.n_kv))
+        return AID_ERR_ARG;
+    if (!a.kv_map && a.n_kv < a.n_frames) return AID_ERR_ARG;
+    if (!aid::attn_head_dim_supported(a.d)) return AID_ERR_SHAPE;
+    if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4 || a.ldvt < a.l) return AID_ERR_SHAPE;
+    if (a.q_fs % 8 || a.k_fs % 8 || a.vt_fs % 8 || a.o_fs % 4) return AID_ERR_SHAPE;
+    if (!aligned16(a.q) || !aligned16(a.k) || !aligned16(a.vt) || !aligned16(a.out)) return AID_ERR_SHAPE;
+    hipError_t e = aid::attn_launch(a, static_cast<hipStream_t>(stream), &g_variant);
+    return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
+}
+
+size_t aid_processor_workspace_bytes(const AidProcessorArgs* args) {
+    if (!args || check_processor(*args) != AID_OK) return 0;
+    return carve(*args).total;
+}
+
+int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
+    if (!args) return AID_ERR_ARG;
+    const AidProcessorArgs& a = *args;
+    int rc = check_processor(a);
+    if (rc != AID_OK) return rc;
+    const Carve cv = carve(a);
+    if (!a.workspace || a.workspace_bytes < cv.total || !aligned16(a.workspace)) return AID_ERR_WORKSPACE;
+    char* ws = static_cast<char*>(a.workspace);
+    void* q = ws + cv.q;
+    void* k = ws + cv.k;
+    void* vt = ws + cv.vt;
+    void* o = ws + cv.o;
+    const bool cross = a.ctx != nullptr;
+    const void* e = cross ? a.ctx : a.x;
+    const int nctx = cross ? a.n_ctx : a.n_frames;
+    const int l = cross ? a.l : a.s;
+    const int cc = cross ? a.cc : a.c;
+    const int d = a.c / a.heads;
+
+    // 1. q, k and V^T projections in one grouped launch
+    AidGemmProblem pr[3];
+    memset(pr, 0, sizeof(pr));
+    pr[0].a = a.x;  pr[0].b = a.wq; pr[0].c = q;
+    pr[0].m = a.n_frames * a.s; pr[0].n = a.c; pr[0].k = a.c;
+    pr[0].lda = a.c; pr[0].ldb = a.c; pr[0].ldc = a.c; pr[0].batch = 1;
+    pr[1].a = e;    pr[1].b = a.wk; pr[1].c = k;
+    pr[1].m = nctx * l; pr[1].n = a.c; pr[1].k = cc;
+    pr[1].lda = cc; pr[1].ldb = cc; pr[1].ldc = a.c; pr[1].batch = 1;
+    pr[2].a = a.wv; pr[2].b = e;    pr[2].c = vt;            // V^T[b] = Wv * E_b^T  -> [c, l]
+    pr[2].m = a.c; pr[2].n = l; pr[2].k = cc;
+    pr[2].lda = cc; pr[2].ldb = cc; pr[2].ldc = cv.lp; pr[2].batch = nctx;
+    pr[2].stride_a = 0; pr[2].stride_b = (int64_t)l * cc; pr[2].stride_c = (int64_t)a.c * cv.lp;
+    rc = aid_gemm_nt(pr, 3, a.dtype, stream);
+    if (rc != AID_OK) return rc;
+
+    // 2. interpolated attention core
+    AidAttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.q = q; at.k = k; at.vt = vt; at.out = o;
+    at.coef = a.coef; at.frame_scale = nullptr; at.kv_map = a.ctx_map;
+    at.n_frames = a.n_frames; at.n_kv = nctx;
+    at.s = a.s; at.l = l; at.heads = a.heads; at.d = d;
+    at.ldq = a.c; at.ldk = a.c; at.ldvt = cv.lp; at.ldo = a.c;
+    at.q_fs = (int64_t)a.s * a.c; at.k_fs = (int64_t)l * a.c; at.vt_fs = (int64_t)a.c * cv.lp; at.o_fs = (int64_t)a.s * a.c;
+    at.mode = a.mode; at.fused = a.fused; at.begin = a.begin; at.end = a.end;
+    at.accumulate = 0; at.dtype = a.dtype;
+    at.softmax_scale = 1.0f / sqrtf((float)d);
+    at.out_scale = 1.0f;
+    rc = aid_attn_fwd(&at, stream);
+    if (rc != AID_OK) return rc;
+
+    // 3. out projection + bias
+    AidGemmProblem po;
+    memset(&po, 0, sizeof(po));
+    po.a = o; po.b = a.wo; po.c = a.y; po.bias = a.bo;
+    po.m = a.n_frames * a.s; po.n = a.c; po.k = a.c;
+    po.lda = a.c; po.ldb = a.c; po.ldc = a.c; po.batch = 1;
+    return aid_gemm_nt(&po, 1, a.dtype, stream);
+}
+
+}  // extern "C"

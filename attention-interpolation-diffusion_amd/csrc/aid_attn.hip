@@ -1,0 +1,409 @@
+// Fused interpolated-attention core for gfx950 (CDNA4): one kernel for the PLAIN / INNER / OUTER
+// modes of the AID processors, with optional fusion of the frame's own keys/values.
+// Replaces, per attention layer call, the reference's end-point select + replicate + concat +
+// baddbmm + softmax + bmm + batch_to_head_dim + lerp chain (interpolation.py:626-664 outer,
+// 760-790 inner; de-activated fallback 581-584) — nothing of [N*H, S, 2L] is ever materialised.
+//
+// Work decomposition: one workgroup = NW waves x 32 query rows of one (frame, head); the grid is
+// ordered [head][frame][q-block] and remapped XCD-aware so all q-blocks of a (frame, head) and the
+// frames of one head (which share the two end-point K/V) hit the same per-XCD L2.
+//
+// Per 64-key tile and wave (MFMA 32x32x16, fp32 accumulate):
+//   S^T[key, q]  = K_tile * Q^T      "swapped" product: lane (q = lane&31, half = lane>>5) owns 32
+//                                    scores of ONE query row -> the row max / row sum of the online
+//                                    softmax are in-lane reductions + one permlane32 swap.
+//   O^T[dv, q]  += Vt_tile * P^T     V is consumed TRANSPOSED ([channel][key], produced that way by
+//                                    the projection GEMM), so both MFMA operands are plain
+//                                    ds_read_b128 row reads; the rescale factor of the online
+//                                    softmax is lane-local because q is the lane index here too.
+//   The K tile is read with key bits 2<->3 swapped so the P registers a lane holds after the first
+//   product are exactly the 8 consecutive keys it must supply as B operand to the second one
+//   (no cross-lane shuffle of P).
+// K / Vt tiles go global -> registers -> LDS (issued before the tile's compute, written after it,
+// two LDS buffers, one barrier per tile); INNER lerps the two end-point tiles in registers on the
+// way (the interpolated K/V never exist in HBM).  LDS rows are padded by 16 B (odd 16-B stride) so
+// all fragment reads are bank-conflict free.
+// OUTER shares the own-keys segment between its two softmaxes (3 segment passes, not 4): the online
+// state after the own segment is snapshotted and continued once with the begin and once with the
+// end frame; frames with coefficient exactly 0 / 1 skip the zero-weighted side.
+#include "aid_common.hpp"
+#include "aid_kernels.hpp"
+
+namespace aid {
+
+constexpr int KT = 64;                  // keys per tile
+constexpr int VLD = KT + 8;             // padded Vt tile row (elements)
+
+struct AttnKParams {
+    AidAttnArgs a;
+    int32_t nqb;                        // q blocks per (frame, head)
+    float   c2;                         // softmax_scale * log2(e)
+};
+
+__host__ __device__ constexpr bool attn_prefetch(int d, int nw) { return nw == 4 && d <= 80; }
+
+template <int NDB>
+struct OState {
+    float  m, l;
+    f32x16 o[NDB];
+};
+
+template <typename T, int D, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) {
+    typedef typename Vec<T>::v8 T8;
+    typedef typename Vec<T>::v4 T4;
+    constexpr int DK = (D + 15) / 16 * 16;      // contraction length of K Q^T (MFMA k = 16)
+    constexpr int DV = (D + 31) / 32 * 32;      // rows of O^T (MFMA m = 32)
+    constexpr int KLD = DK + 8;                 // padded K tile row (elements); KLD/8 is odd
+    constexpr int NQK = DK / 16, NDB = DV / 32;
+    constexpr int NT = NW * 64;
+    constexpr int DC = D / 8;                   // 16-B chunks per K row
+    constexpr int NKC = (KT * DC + NT - 1) / NT;        // K chunks per thread per tile
+    constexpr int NVC = (D * (KT / 8) + NT - 1) / NT;   // Vt chunks per thread per tile
+    // Prefetch (issue tile t+1's loads before tile t's compute, two LDS buffers) only where the staging
+    // registers fit beside the accumulators; otherwise stage synchronously through one buffer.
+    constexpr bool PREFETCH = attn_prefetch(D, NW);
+    constexpr int NBUF = PREFETCH ? 2 : 1;
+    static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+    static_assert((KLD / 8) % 2 == 1 && (VLD / 8) % 2 == 1, "LDS row stride must be an odd number of 16-B slots");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);             // [NBUF][KT][KLD]
+    T* Vs = Ks + NBUF * KT * KLD;                       // [NBUF][DV][VLD]
+
+    const AidAttnArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = lid % p.nqb;
+    const int fr = (lid / p.nqb) % a.n_frames;
+    const int h = lid / (p.nqb * a.n_frames);
+    const int q0 = (qb * NW + wave) * 32;
+
+    // zero both LDS buffers once: pad columns / pad rows are never staged and must be finite
+    for (int i = tid; i < NBUF * (KT * KLD + DV * VLD) / 8; i += NT)
+        reinterpret_cast<T8*>(Ks)[i] = zero8<T>();
+
+    // ---- Q fragments (B operand of the swapped product), straight from global -------------
+    T8 qf[NQK];
+    {
+        const T* qrow = reinterpret_cast<const T*>(a.q) + (int64_t)fr * a.q_fs + (int64_t)(q0 + l31) * a.ldq + h * D;
+        const bool rowok = (q0 + l31) < a.s;
+#pragma unroll
+        for (int ks = 0; ks < NQK; ++ks) {
+            const int col = ks * 16 + hi * 8;
+            qf[ks] = (rowok && col < D) ? *reinterpret_cast<const T8*>(qrow + col) : zero8<T>();
+        }
+    }
+    __syncthreads();
+
+    const int kvf = a.kv_map ? a.kv_map[fr] : fr;
+    const float cf = (MODE == AID_MODE_PLAIN || a.coef == nullptr) ? 0.f : a.coef[fr];
+    const T* Kg = reinterpret_cast<const T*>(a.k) + h * D;
+    const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)(h * D) * a.ldvt;
+    const int L = a.l;
+    const float c2 = p.c2;
+
+    // ---- one segment of keys: online-softmax update of `st` ----------------------------------
+    // k0/v0: frame base pointers (already offset to head h); k1/v1 + c: lerp partner (INNER).
+    auto run = [&](OState<NDB>& st, const T* k0, const T* v0, const T* k1, const T* v1, const bool lerp,
+                   const float c) __attribute__((always_inline)) {
+        T8 rk[NKC], rv[NVC], rk1[NKC], rv1[NVC];
+        auto stage_load = [&](int key0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NKC; ++i) {
+                const int id = tid + i * NT;
+                const int row = id / DC, cc = id % DC;
+                const bool ok = (id < KT * DC) && (key0 + row) < L;
+                const int64_t off = (int64_t)(key0 + row) * a.ldk + cc * 8;
+                rk[i] = ok ? *reinterpret_cast<const T8*>(k0 + off) : zero8<T>();
+                if (lerp) rk1[i] = ok ? *reinterpret_cast<const T8*>(k1 + off) : zero8<T>();
+            }
+#pragma unroll
+            for (int i = 0; i < NVC; ++i) {
+                const int id = tid + i * NT;
+                const int row = id / (KT / 8), kc = key0 + (id % (KT / 8)) * 8;
+                const bool ok = (id < D * (KT / 8)) && kc < a.ldvt && kc < L;
+                const int64_t off = (int64_t)row * a.ldvt + kc;
+                rv[i] = ok ? *reinterpret_cast<const T8*>(v0 + off) : zero8<T>();
+                if (lerp) rv1[i] = ok ? *reinterpret_cast<const T8*>(v1 + off) : zero8<T>();
+            }
+        };
+        auto stage_write = [&](int buf, int key0) __attribute__((always_inline)) {
+            T* ks = Ks + buf * KT * KLD;
+            T* vs = Vs + buf * DV * VLD;
+#pragma unroll
+            for (int i = 0; i < NKC; ++i) {
+                const int id = tid + i * NT;
+                if (id >= KT * DC) continue;
+                T8 v = rk[i];
+                if (lerp) {
+                    const f32x8 x0 = up8<T>(rk[i]), x1 = up8<T>(rk1[i]);
+                    f32x8 y;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = fmaf(c, x1[e], (1.f - c) * x0[e]);
+                    v = cvt8<T>(y);
+                }
+                *reinterpret_cast<T8*>(ks + (id / DC) * KLD + (id % DC) * 8) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NVC; ++i) {
+                const int id = tid + i * NT;
+                if (id >= D * (KT / 8)) continue;
+                const int kc = key0 + (id % (KT / 8)) * 8;
+                T8 v = rv[i];
+                if (lerp) {
+                    const f32x8 x0 = up8<T>(rv[i]), x1 = up8<T>(rv1[i]);
+                    f32x8 y;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = fmaf(c, x1[e], (1.f - c) * x0[e]);
+                    v = cvt8<T>(y);
+                }
+                if (kc + 8 > L) {                                   // chunk straddles the end of the keys
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (kc + e >= L) v[e] = (T)0.0f;
+                }
+                *reinterpret_cast<T8*>(vs + (id / (KT / 8)) * VLD + (id % (KT / 8)) * 8) = v;
+            }
+        };
+
+        const int nt = (L + KT - 1) / KT;
+        if (PREFETCH) {
+            stage_load(0);
+            stage_write(0, 0);
+            __syncthreads();
+        }
+        // key bits 2<->3 swapped: MFMA row i of the score block reads LDS key row pi(i)
+        const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+
+        for (int t = 0; t < nt; ++t) {
+            const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
+            if (PREFETCH) {
+                if (t + 1 < nt) stage_load(key0 + KT);
+            } else {
+                stage_load(key0);
+                stage_write(0, key0);
+                __syncthreads();
+            }
+            const int nb = (L - key0 > 32) ? 2 : 1;               // 32-key blocks with any valid key
+
+            // ---- S^T = K Q^T ------------------------------------------------------------------
+            f32x16 sc[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[b][r] = 0.f;
+            const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b < nb) {
+#pragma unroll
+                    for (int ks = 0; ks < NQK; ++ks) {
+                        const T8 ka = *reinterpret_cast<const T8*>(kt + b * 32 * KLD + ks * 16);
+                        sc[b] = mfma32(ka, qf[ks], sc[b]);
+                    }
+                }
+            }
+            // lane (q, hi): sc[b][r] is the score of key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
+            if (key0 + KT > L) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key0 + 32 * b + 16 * (r >> 3) + 8 * hi + (r & 7) >= L) sc[b][r] = -INFINITY;
+            }
+            // ---- online softmax (base-2 domain) --------------------------------------------------
+            float tmax = sc[0][0];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[b][r]);
+            tmax = max_halves(tmax);
+            const float m_new = fmaxf(st.m, tmax);
+            const float alpha = __builtin_amdgcn_exp2f((st.m - m_new) * c2);
+            const float mc = m_new * c2;
+            st.m = m_new;
+            float psum = 0.f;
+            T8 pf[4];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x8 pv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        pv[e] = __builtin_amdgcn_exp2f(fmaf(sc[b][8 * u + e], c2, -mc));
+                        psum += pv[e];
+                    }
+                    pf[2 * b + u] = cvt8<T>(pv);
+                }
+            st.l = st.l * alpha + psum;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st.o[d][r] *= alpha;
+
+            // ---- O^T += Vt P^T --------------------------------------------------------------------
+            const T* vt = Vs + buf * DV * VLD + l31 * VLD + hi * 8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk < 2 * nb) {
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) {
+                        const T8 va = *reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16);
+                        st.o[d] = mfma32(va, pf[kk], st.o[d]);
+                    }
+                }
+            }
+            if (PREFETCH && t + 1 < nt) stage_write(buf ^ 1, key0 + KT);
+            __syncthreads();
+        }
+    };
+
+    auto init = [&](OState<NDB>& st) {
+        st.m = -1e30f;
+        st.l = 0.f;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[d][r] = 0.f;
+    };
+
+    const T* k_own = Kg + (int64_t)kvf * a.k_fs;
+    const T* v_own = Vg + (int64_t)kvf * a.vt_fs;
+    const T* k_beg = Kg + (int64_t)a.begin * a.k_fs;
+    const T* v_beg = Vg + (int64_t)a.begin * a.vt_fs;
+    const T* k_end = Kg + (int64_t)a.end * a.k_fs;
+    const T* v_end = Vg + (int64_t)a.end * a.vt_fs;
+
+    OState<NDB> st;
+    init(st);
+    f32x16 res[NDB];
+
+    if (MODE == AID_MODE_PLAIN) {
+        run(st, k_own, v_own, nullptr, nullptr, false, 0.f);
+        const float inv = 1.f / sum_halves(st.l);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
+    } else if (MODE == AID_MODE_INNER) {
+        if (a.fused) run(st, k_own, v_own, nullptr, nullptr, false, 0.f);
+        // coefficient exactly 0 / 1: the lerp is the end-point frame itself
+        if (cf == 0.f)      run(st, k_beg, v_beg, nullptr, nullptr, false, 0.f);
+        else if (cf == 1.f) run(st, k_end, v_end, nullptr, nullptr, false, 0.f);
+        else                run(st, k_beg, v_beg, k_end, v_end, true, cf);
+        const float inv = 1.f / sum_halves(st.l);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
+    } else {
+        if (a.fused) run(st, k_own, v_own, nullptr, nullptr, false, 0.f);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[d][r] = 0.f;
+        if (cf != 1.f) {                                    // begin side, weight (1 - c)
+            OState<NDB> sb = st;
+            run(sb, k_beg, v_beg, nullptr, nullptr, false, 0.f);
+            const float w = (1.f - cf) / sum_halves(sb.l);
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) res[d] = sb.o[d] * w;
+        }
+        if (cf != 0.f) {                                    // end side, weight c
+            run(st, k_end, v_end, nullptr, nullptr, false, 0.f);
+            const float w = cf / sum_halves(st.l);
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) res[d] += st.o[d] * w;
+        }
+    }
+
+    // ---- epilogue: lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3} ------------------------
+    const int q = q0 + l31;
+    if (q < a.s) {
+        const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
+        T* orow = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q * a.ldo + h * D;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dv = 32 * d + 8 * g + 4 * hi;
+                if (dv < D) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = res[d][4 * g + e] * osc;
+                    if (a.accumulate) {
+                        const f32x4 old = up4<T>(*reinterpret_cast<const T4*>(orow + dv));
+                        v += old;
+                    }
+                    *reinterpret_cast<T4*>(orow + dv) = cvt4<T>(v);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, int MODE, int NW>
+static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
+    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
+    const size_t smem = (size_t)(attn_prefetch(D, NW) ? 2 : 1) * (KT * (DK + 8) + DV * VLD) * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = p.nqb * p.a.n_frames * p.a.heads;
+    hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW>), dim3(grid), dim3(NW * 64), smem, stream, p);
+    return hipGetLastError();
+}
+
+template <typename T, int D, int MODE>
+static hipError_t launch_nw(AttnKParams& p, hipStream_t stream, int* nw_out) {
+    // small images: one wave per workgroup so the grid still covers the 256 CUs
+    const int nw = (p.a.s * p.a.n_frames * p.a.heads >= 128 * 512) ? 4 : 1;
+    *nw_out = nw;
+    p.nqb = (p.a.s + 32 * nw - 1) / (32 * nw);
+    return nw == 4 ? launch_variant<T, D, MODE, 4>(p, stream) : launch_variant<T, D, MODE, 1>(p, stream);
+}
+
+template <typename T, int D>
+static hipError_t launch_mode(AttnKParams& p, hipStream_t stream, int* nw_out) {
+    switch (p.a.mode) {
+        case AID_MODE_PLAIN: return launch_nw<T, D, AID_MODE_PLAIN>(p, stream, nw_out);
+        case AID_MODE_INNER: return launch_nw<T, D, AID_MODE_INNER>(p, stream, nw_out);
+        default:             return launch_nw<T, D, AID_MODE_OUTER>(p, stream, nw_out);
+    }
+}
+
+template <typename T>
+static hipError_t launch_d(AttnKParams& p, hipStream_t stream, int* nw_out) {
+    switch (p.a.d) {
+        case 40:  return launch_mode<T, 40>(p, stream, nw_out);
+        case 64:  return launch_mode<T, 64>(p, stream, nw_out);
+        case 80:  return launch_mode<T, 80>(p, stream, nw_out);
+        case 160: return launch_mode<T, 160>(p, stream, nw_out);
+        default:  return hipErrorInvalidValue;
+    }
+}
+
+bool attn_head_dim_supported(int d) { return d == 40 || d == 64 || d == 80 || d == 160; }
+
+hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** variant) {
+    AttnKParams p;
+    p.a = a;
+    p.nqb = 0;
+    p.c2 = a.softmax_scale * 1.4426950408889634f;
+    int nw = 0;
+    hipError_t e = (a.dtype == AID_DTYPE_F16) ? launch_d<f16>(p, stream, &nw) : launch_d<bf16>(p, stream, &nw);
+    if (variant) {
+        static thread_local char name[64];
+        static const char* modes[] = {"plain", "inner", "outer"};
+        snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
+                 modes[a.mode], nw);
+        *variant = name;
+    }
+    return e;
+}
+
+}  // namespace aid

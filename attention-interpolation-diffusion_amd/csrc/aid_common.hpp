@@ -1,0 +1,92 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aid {
+
+typedef _Float16 f16;
+typedef __bf16   bf16;
+
+template <typename T> struct Vec;
+template <> struct Vec<f16> {
+    typedef f16 v2 __attribute__((ext_vector_type(2)));
+    typedef f16 v4 __attribute__((ext_vector_type(4)));
+    typedef f16 v8 __attribute__((ext_vector_type(8)));
+};
+template <> struct Vec<bf16> {
+    typedef bf16 v2 __attribute__((ext_vector_type(2)));
+    typedef bf16 v4 __attribute__((ext_vector_type(4)));
+    typedef bf16 v8 __attribute__((ext_vector_type(8)));
+};
+
+typedef float f32x2  __attribute__((ext_vector_type(2)));
+typedef float f32x4  __attribute__((ext_vector_type(4)));
+typedef float f32x8  __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// D(32x32, fp32) += A(32x16) * B(16x32).  Lane l supplies A[i = l&31][8*(l>>5) .. +7] and
+// B[8*(l>>5) .. +7][j = l&31]; lane l receives D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31], r in [0,16).
+__device__ __forceinline__ f32x16 mfma32(const Vec<f16>::v8& a, const Vec<f16>::v8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(const Vec<bf16>::v8& a, const Vec<bf16>::v8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 zero8() {
+    typename Vec<T>::v8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (T)0.0f;
+    return z;
+}
+
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v8 cvt8(const f32x8& x) {
+    return __builtin_convertvector(x, typename Vec<T>::v8);     // v_cvt_pk_{f16,bf16}_f32, RNE
+}
+template <typename T>
+__device__ __forceinline__ f32x8 up8(const typename Vec<T>::v8& x) {
+    return __builtin_convertvector(x, f32x8);
+}
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::v4 cvt4(const f32x4& x) {
+    return __builtin_convertvector(x, typename Vec<T>::v4);
+}
+template <typename T>
+__device__ __forceinline__ f32x4 up4(const typename Vec<T>::v4& x) {
+    return __builtin_convertvector(x, f32x4);
+}
+
+// value held by the partner lane (lane ^ 32)
+__device__ __forceinline__ float other_half(float x) {
+    const uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    // lanes < 32 find the partner's value in r[1], lanes >= 32 in r[0]
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float max_halves(float x) {
+    const uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_halves(float x) {
+    const uint32_t u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Bijective XCD-aware remap of a 1-D grid: hardware places block b on XCD b % 8; give every
+// XCD a contiguous range of logical ids so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    constexpr int NX = 8;
+    const int q = nblocks / NX, r = nblocks % NX;
+    const int x = bid % NX, j = bid / NX;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + j;
+}
+
+}  // namespace aid

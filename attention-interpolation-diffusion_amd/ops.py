@@ -1,0 +1,207 @@
+"""Tensor-level entry points over the C ABI (device pointers taken from torch tensors).
+
+PyTorch is plumbing here: it owns device memory and the stream; every FLOP is executed by
+``libaid_hip.so``.  All functions enqueue on ``torch.cuda.current_stream()`` and never
+synchronise.  Tensors must live on a HIP device and be fp16 / bf16 — anything else raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (DTYPE_BF16, DTYPE_F16, MODE_INNER, MODE_OUTER, MODE_PLAIN, AidAttnArgs,
+                   AidGemmProblem, AidProcessorArgs)
+
+MODES = {"plain": MODE_PLAIN, "inner": MODE_INNER, "outer": MODE_OUTER}
+SUPPORTED_HEAD_DIMS = (40, 64, 80, 160)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float16:
+        return DTYPE_F16
+    if t.dtype == torch.bfloat16:
+        return DTYPE_BF16
+    raise TypeError(f"the HIP path computes in float16 / bfloat16; got {t.dtype} "
+                    "(cast the model, e.g. unet.to(torch.float16))")
+
+
+def _require_gpu(*ts: Optional[torch.Tensor]) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("attention-interpolation-diffusion_amd has no CPU path: tensors must be on "
+                               f"an MI355X (HIP) device, got device={t.device}")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    """Scratch buffer cached per (device, stream); kernels on one stream run in order, so reuse is safe."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm_nt(problems: Sequence[dict]) -> None:
+    """Grouped C = A @ B^T (+ bias).  Each problem: dict(a=[.., m, k], b=[n, k] or [batch, n, k],
+    c=out tensor, bias=None|[n], batch=1, m, n, k, lda, ldb, ldc, stride_a, stride_b, stride_c)."""
+    lib = _lib.load()
+    n = len(problems)
+    arr = (AidGemmProblem * n)()
+    dt = None
+    for i, p in enumerate(problems):
+        _require_gpu(p["a"], p["b"], p["c"], p.get("bias"))
+        code = _dtype_code(p["a"])
+        if dt is None:
+            dt = code
+        if code != dt or _dtype_code(p["b"]) != dt or _dtype_code(p["c"]) != dt:
+            raise TypeError("all GEMM operands must share one dtype")
+        q = arr[i]
+        q.a, q.b, q.c = p["a"].data_ptr(), p["b"].data_ptr(), p["c"].data_ptr()
+        q.bias = _ptr(p.get("bias"))
+        q.m, q.n, q.k = p["m"], p["n"], p["k"]
+        q.lda, q.ldb, q.ldc = p["lda"], p["ldb"], p["ldc"]
+        q.batch = p.get("batch", 1)
+        q.stride_a, q.stride_b, q.stride_c = p.get("stride_a", 0), p.get("stride_b", 0), p.get("stride_c", 0)
+    _lib.check(lib.aid_gemm_nt(arr, n, dt, _stream()), "aid_gemm_nt")
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ w.T + bias on the HIP GEMM (x [..., k] contiguous, w [n, k] contiguous)."""
+    assert x.is_contiguous() and w.is_contiguous()
+    k = x.shape[-1]
+    n = w.shape[0]
+    m = x.numel() // k
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    gemm_nt([dict(a=x, b=w, c=out, bias=bias, m=m, n=n, k=k, lda=k, ldb=k, ldc=n)])
+    return out
+
+
+def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """k = e @ wk.T  [F, L, C]  and  V^T = wv @ e^T  [F, C, Lp]  (Lp = L rounded up to 8) in one launch."""
+    f, l, cc = e.shape
+    c = wk.shape[0]
+    lp = (l + 7) // 8 * 8
+    k = torch.empty(f, l, c, dtype=e.dtype, device=e.device)
+    vt = torch.empty(f, c, lp, dtype=e.dtype, device=e.device)
+    gemm_nt([
+        dict(a=e, b=wk, c=k, m=f * l, n=c, k=cc, lda=cc, ldb=cc, ldc=c),
+        dict(a=wv, b=e, c=vt, m=c, n=l, k=cc, lda=cc, ldb=cc, ldc=lp, batch=f,
+             stride_a=0, stride_b=l * cc, stride_c=c * lp),
+    ])
+    return k, vt
+
+
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, l: int,
+             mode: str = "plain", fused: bool = False, coef: Optional[torch.Tensor] = None,
+             begin: int = 0, end: int = -1, out: Optional[torch.Tensor] = None,
+             accumulate: bool = False, out_scale: float = 1.0,
+             frame_scale: Optional[torch.Tensor] = None, kv_map: Optional[torch.Tensor] = None,
+             softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """Interpolated attention core (see AidAttnArgs in include/aid_hip.h).
+    q [N, S, C], k [F, L, C], vt [F, C, Lp] contiguous; coef / frame_scale fp32 device [N]."""
+    lib = _lib.load()
+    _require_gpu(q, k, vt, out, coef, frame_scale, kv_map)
+    dt = _dtype_code(q)
+    if _dtype_code(k) != dt or _dtype_code(vt) != dt:
+        raise TypeError("q, k, vt must share one dtype")
+    assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    n, s, c = q.shape
+    f = k.shape[0]
+    d = c // heads
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs an existing `out`")
+        out = torch.empty_like(q)
+    for t_, nm in ((coef, "coef"), (frame_scale, "frame_scale")):
+        if t_ is not None and (t_.dtype != torch.float32 or t_.numel() != n):
+            raise ValueError(f"{nm} must be a float32 device tensor with one entry per frame ({n})")
+    if kv_map is not None and (kv_map.dtype != torch.int32 or kv_map.numel() != n):
+        raise ValueError("kv_map must be an int32 device tensor with one entry per frame")
+    a = AidAttnArgs()
+    a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    a.coef, a.frame_scale, a.kv_map = _ptr(coef), _ptr(frame_scale), _ptr(kv_map)
+    a.n_frames, a.n_kv = n, f
+    a.s, a.l, a.heads, a.d = s, l, heads, d
+    a.ldq, a.ldk, a.ldvt, a.ldo = c, k.shape[2], vt.shape[2], out.shape[2]
+    a.q_fs, a.k_fs, a.vt_fs, a.o_fs = s * c, k.shape[1] * k.shape[2], vt.shape[1] * vt.shape[2], s * out.shape[2]
+    a.mode, a.fused = MODES[mode], int(bool(fused))
+    a.begin, a.end = begin % f, end % f
+    a.accumulate, a.dtype = int(bool(accumulate)), dt
+    a.softmax_scale = float(d ** -0.5 if softmax_scale is None else softmax_scale)
+    a.out_scale = float(out_scale)
+    _lib.check(lib.aid_attn_fwd(C.byref(a), _stream()), "aid_attn_fwd")
+    return out
+
+
+def last_attn_variant() -> str:
+    return _lib.load().aid_last_attn_variant().decode()
+
+
+def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor, wk: torch.Tensor,
+                  wv: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], heads: int, *,
+                  mode: str = "plain", fused: bool = False, coef: Optional[torch.Tensor] = None,
+                  begin: int = 0, end: int = -1, ctx_map: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One whole processor call: y = to_out(AID-attention(to_q(x), to_k(ctx), to_v(ctx)))
+    in three launches (grouped q/k/V^T GEMM, attention core, out-proj GEMM)."""
+    lib = _lib.load()
+    dev = _require_gpu(x, ctx, wq, wk, wv, wo, bo, coef, ctx_map, out)
+    dt = _dtype_code(x)
+    for t_ in (ctx, wq, wk, wv, wo, bo):
+        if t_ is not None and t_.dtype != x.dtype:
+            raise TypeError(f"dtype mismatch: hidden states are {x.dtype}, another operand is {t_.dtype}")
+    for t_ in (x, ctx, wq, wk, wv, wo, bo):
+        if t_ is not None and not t_.is_contiguous():
+            raise ValueError("operands must be contiguous")
+    n, s, c = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    a = AidProcessorArgs()
+    a.x, a.ctx = x.data_ptr(), _ptr(ctx)
+    a.wq, a.wk, a.wv, a.wo, a.bo = wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), wo.data_ptr(), _ptr(bo)
+    a.y, a.coef, a.ctx_map = out.data_ptr(), _ptr(coef), _ptr(ctx_map)
+    a.n_frames, a.s, a.c, a.heads = n, s, c, heads
+    if ctx is not None:
+        a.n_ctx, a.l, a.cc = ctx.shape
+    else:
+        a.n_ctx, a.l, a.cc = n, s, c
+    nkv = a.n_ctx
+    a.mode, a.fused = MODES[mode], int(bool(fused))
+    a.begin, a.end = begin % nkv, end % nkv
+    a.dtype = dt
+    nbytes = lib.aid_processor_workspace_bytes(C.byref(a))
+    if nbytes == 0:
+        # let the library say why
+        a.workspace, a.workspace_bytes = None, 0
+        _lib.check(lib.aid_processor_fwd(C.byref(a), _stream()), "aid_processor_fwd")
+        raise RuntimeError("aid_processor_workspace_bytes returned 0")
+    ws = workspace(nbytes, dev)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    _lib.check(lib.aid_processor_fwd(C.byref(a), _stream()), "aid_processor_fwd")
+    return out

@@ -1,0 +1,164 @@
+/*
+ * aid_hip.h — C ABI of libaid_hip.so: the MI355X (gfx950 / CDNA4) implementation of the
+ * interpolated-attention hot path of QY-H00/attention-interpolation-diffusion.
+ *
+ * Plain pointers and sizes only: no torch / HIP types appear in any signature, so the
+ * library can be bound from ctypes (what this repository's Python processors do), cffi,
+ * pybind11 or any other FFI.  All pointers are DEVICE pointers unless stated otherwise;
+ * `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ * Every entry point only enqueues work on `stream`: no allocation, no host
+ * synchronisation, no hidden copies.  Return value: AID_OK (0) or a negative AID_ERR_*
+ * code; aid_strerror() gives the text.  No C++ exception crosses this boundary.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   aid_processor_fwd      <- InterpolatedAttnProcessor family __call__ bodies:
+ *                             OuterInterpolatedAttnProcessor   interpolation.py:573-679
+ *                             InnerInterpolatedAttnProcessor   interpolation.py:707-804
+ *                             de-activated fallback (AttnProcessor2_0)  interpolation.py:581-584
+ *                             IP variants are composed from two calls of aid_attn_fwd
+ *                             (interpolation.py:240-387, 417-545, 76-211)
+ *   aid_gemm_nt            <- attn.to_q / to_k / to_v / to_out[0]   interpolation.py:613,623-624,666
+ *   aid_attn_fwd           <- end-point select / replicate / concat / get_attention_scores /
+ *                             bmm / batch_to_head_dim / outer|inner lerp
+ *                             interpolation.py:626-664 (outer), 760-790 (inner)
+ */
+#ifndef AID_HIP_H
+#define AID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AID_ABI_VERSION 1
+
+/* element types of activations / weights (accumulation is always fp32) */
+#define AID_DTYPE_F16  0
+#define AID_DTYPE_BF16 1
+
+/* attention modes */
+#define AID_MODE_PLAIN 0   /* softmax(Q K_i^T) V_i                       (AID de-activated)          */
+#define AID_MODE_INNER 1   /* keys/values lerped between the end-point frames before attention     */
+#define AID_MODE_OUTER 2   /* attention against each end-point frame, outputs lerped               */
+
+/* error codes */
+#define AID_OK             0
+#define AID_ERR_ARG       -1   /* NULL pointer / negative size / inconsistent field              */
+#define AID_ERR_DTYPE     -2   /* dtype not one of AID_DTYPE_*                                    */
+#define AID_ERR_SHAPE     -3   /* unsupported head dim / alignment (see each function)            */
+#define AID_ERR_WORKSPACE -4   /* workspace too small                                             */
+#define AID_ERR_LAUNCH    -5   /* hipLaunchKernel failed (hipGetLastError text via aid_strerror)  */
+#define AID_ERR_NO_DEVICE -6   /* no gfx950 device visible                                        */
+
+/* ---------------------------------------------------------------------------------------
+ * Grouped "NT" GEMM:   C[b] = A[b] * B[b]^T (+ bias)        for b in [0, batch)
+ *   A [m, k] row-major (lda), B [n, k] row-major (ldb)  -> both operands K-contiguous,
+ *   C [m, n] row-major (ldc).  bias (optional) is indexed by n and has the operand dtype.
+ *   Up to AID_GEMM_MAX_PROBLEMS independent problems run in ONE launch (q, k and V^T
+ *   projections of an attention layer).
+ *   Requirements: k % 8 == 0, lda % 8 == 0, ldb % 8 == 0, ldc % 4 == 0, ldc >= round_up(n, 4),
+ *   all base pointers 16-byte aligned.  Columns [n, round_up(n,4)) of C are written with zeros.
+ * ------------------------------------------------------------------------------------- */
+#define AID_GEMM_MAX_PROBLEMS 4
+
+typedef struct AidGemmProblem {
+    const void* a;
+    const void* b;
+    void*       c;
+    const void* bias;          /* NULL = none */
+    int32_t     m, n, k;
+    int32_t     lda, ldb, ldc; /* in elements */
+    int32_t     batch;         /* >= 1 */
+    int32_t     _pad;
+    int64_t     stride_a, stride_b, stride_c;   /* per-batch strides in elements (0 = shared) */
+} AidGemmProblem;
+
+int aid_gemm_nt(const AidGemmProblem* problems /* host */, int n_problems, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Interpolated attention core on projected tensors.
+ *   q   [n_frames, s, heads*d]        row stride ldq, frame stride q_fs   (elements)
+ *   k   [n_kv,     l, heads*d]        row stride ldk, frame stride k_fs
+ *   vt  [n_kv, heads*d, ldvt]         V TRANSPOSED (channel-major): vt[f][c][key]; ldvt >= l,
+ *                                     ldvt % 8 == 0, frame stride vt_fs
+ *   out [n_frames, s, heads*d]        row stride ldo, frame stride o_fs
+ * Frame i attends with its own keys  K[kv_of(i)]  (kv_of = kv_map[i] if kv_map else i) and with
+ * the end-point frames K[begin], K[end]:
+ *   PLAIN : O_i = A(Q_i, K_i, V_i)
+ *   INNER : Kc = (1-c_i) K[begin] + c_i K[end]  (same for V);
+ *           O_i = fused ? A(Q_i, [K_i ; Kc], [V_i ; Vc]) : A(Q_i, Kc, Vc)
+ *   OUTER : O_i = (1-c_i) A(Q_i, [K_i;] K[begin], ..) + c_i A(Q_i, [K_i;] K[end], ..)
+ * with A(Q,K,V) = softmax(Q K^T * softmax_scale) V per head, c_i = coef[i] (fp32, device).
+ * Finally   out_i = (accumulate ? out_i : 0) + out_scale * (frame_scale ? frame_scale[i] : 1) * O_i.
+ * Supported head dims d: 40, 64, 80, 160 (SD1.5 / SDXL).  No sequence-length restriction.
+ * ------------------------------------------------------------------------------------- */
+typedef struct AidAttnArgs {
+    const void*    q;
+    const void*    k;
+    const void*    vt;
+    void*          out;
+    const float*   coef;         /* device [n_frames]; may be NULL for PLAIN                 */
+    const float*   frame_scale;  /* device [n_frames] or NULL                                */
+    const int32_t* kv_map;       /* device [n_frames] or NULL (identity)                     */
+    int32_t n_frames, n_kv;
+    int32_t s, l, heads, d;
+    int32_t ldq, ldk, ldvt, ldo;
+    int64_t q_fs, k_fs, vt_fs, o_fs;
+    int32_t mode;                /* AID_MODE_*                                               */
+    int32_t fused;               /* 0/1: prepend the frame's own keys/values                 */
+    int32_t begin, end;          /* end-point frame indices into k / vt                      */
+    int32_t accumulate;          /* 0/1                                                      */
+    int32_t dtype;               /* AID_DTYPE_*                                              */
+    float   softmax_scale;       /* d^-0.5 for diffusers Attention                           */
+    float   out_scale;
+} AidAttnArgs;
+
+int aid_attn_fwd(const AidAttnArgs* args /* host */, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One whole processor call (what diffusers' Attention.forward hands to the AID processor):
+ *   x   [n_frames, s, c]   hidden states          ctx [n_frames, l, cc] or NULL (self-attn: ctx = x)
+ *   wq [c, c]  wk [c, cc]  wv [c, cc]  wo [c, c]  bo [c]      (torch Linear.weight layout [out, in])
+ *   y   [n_frames, s, c]   = to_out( AID-attention( to_q(x), to_k(ctx), to_v(ctx) ) )
+ * Launches: 1 grouped GEMM (q, k, V^T), 1 attention kernel, 1 GEMM (out-proj + bias).
+ * `workspace` must hold aid_processor_workspace_bytes() bytes (16-byte aligned); it is
+ * scratch, owned by the caller, and may be reused by the next call on the same stream.
+ * ------------------------------------------------------------------------------------- */
+typedef struct AidProcessorArgs {
+    const void*  x;
+    const void*  ctx;            /* NULL => self-attention                                   */
+    const void*  wq;
+    const void*  wk;
+    const void*  wv;
+    const void*  wo;
+    const void*  bo;             /* NULL = no bias                                           */
+    void*        y;
+    const float* coef;           /* device [n_frames] (already rounded to the compute dtype, */
+                                 /* interpolation.py:663); NULL for PLAIN                    */
+    void*        workspace;
+    size_t       workspace_bytes;
+    int32_t n_frames, s, l, c, cc, heads;
+    int32_t mode, fused;
+    int32_t begin, end;          /* end-point frames (reference: 0 and n_frames-1)           */
+    int32_t dtype;
+    int32_t n_ctx;               /* number of ctx frames (n_frames, or fewer with ctx_map)   */
+    const int32_t* ctx_map;      /* device [n_frames] frame -> ctx row, or NULL (identity)   */
+} AidProcessorArgs;
+
+size_t aid_processor_workspace_bytes(const AidProcessorArgs* args /* host */);
+int    aid_processor_fwd(const AidProcessorArgs* args /* host */, void* stream);
+
+/* misc */
+int         aid_abi_version(void);
+const char* aid_strerror(int code);
+/* name of the kernel variant the last aid_attn_fwd call on this thread launched (for profiling) */
+const char* aid_last_attn_variant(void);
+/* device properties of the current device: returns AID_OK and fills what is non-NULL */
+int aid_device_info(int* n_cu, int* clock_khz, char* arch /* >= 32 bytes */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AID_HIP_H */
