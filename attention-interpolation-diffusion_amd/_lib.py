@@ -24,6 +24,7 @@ GEMM_MAX_PROBLEMS = 4
 ABI_SYMBOLS = (
     "aid_gemm_nt", "aid_attn_fwd", "aid_processor_workspace_bytes", "aid_processor_fwd",
     "aid_abi_version", "aid_strerror", "aid_last_attn_variant", "aid_device_info",
+    "aid_profile_begin", "aid_profile_end",
 )
 
 
@@ -61,6 +62,10 @@ class AidProcessorArgs(C.Structure):
         ("begin", C.c_int32), ("end", C.c_int32), ("dtype", C.c_int32), ("n_ctx", C.c_int32),
         ("ctx_map", C.c_void_p),
     ]
+
+
+class AidProfileEntry(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -102,6 +107,9 @@ def load() -> C.CDLL:
     lib.aid_processor_workspace_bytes.argtypes = [C.POINTER(AidProcessorArgs)]
     lib.aid_processor_fwd.restype = C.c_int
     lib.aid_processor_fwd.argtypes = [C.POINTER(AidProcessorArgs), C.c_void_p]
+    lib.aid_profile_begin.restype = C.c_int
+    lib.aid_profile_end.restype = C.c_int
+    lib.aid_profile_end.argtypes = [C.POINTER(AidProfileEntry), C.c_int]
     if lib.aid_abi_version() != AID_ABI_VERSION:
         raise RuntimeError(f"libaid_hip.so ABI version {lib.aid_abi_version()} != expected {AID_ABI_VERSION}; rebuild")
     _lib = lib

@@ -140,15 +140,17 @@ class AttnStackUNet(nn.Module):
     """
 
     def __init__(self, model: str = "sd15", dtype=torch.float16, device=None, seed: int = 1002,
-                 scale_down: int = 1):
+                 scale_down: int = 1, channel_div: int = 1):
+        """``scale_down`` divides every S, ``channel_div`` every width (structure-only uses in tests)."""
         super().__init__()
         spec = MODEL_SPECS[model]
         self.model = model
-        self.cross_dim = spec["cross_dim"]
+        self.cross_dim = spec["cross_dim"] // channel_div
         self.text_len = spec["text_len"]
         names, mods, shapes = [], [], []
         for loc, nblk, s, c, h in spec["layers"]:
             s = max(s // scale_down, 1)
+            c = c // channel_div
             for b in range(nblk):
                 for which, cd in (("attn1", None), ("attn2", self.cross_dim)):
                     names.append(f"{loc}.attentions.{b}.transformer_blocks.0.{which}.processor")
@@ -157,13 +159,15 @@ class AttnStackUNet(nn.Module):
         self.names = names
         self.layers = nn.ModuleList(mods)
         self.shapes = shapes
-        g = torch.Generator(device="cpu").manual_seed(seed)
-        with torch.no_grad():                              # weights ~ N(0, 1/fan_in), bias ~ N(0, .01)
+        # weights ~ N(0, 1/fan_in), bias ~ N(0, .01); generated on the target device
+        gdev = self.layers[0].to_q.weight.device
+        g = torch.Generator(device=gdev).manual_seed(seed)
+        with torch.no_grad():
             for m in self.layers:
                 for lin in (m.to_q, m.to_k, m.to_v, m.to_out[0]):
-                    w = torch.randn(lin.weight.shape, generator=g) / lin.weight.shape[1] ** 0.5
+                    w = torch.randn(lin.weight.shape, generator=g, device=gdev) / lin.weight.shape[1] ** 0.5
                     lin.weight.copy_(w.to(lin.weight.dtype))
-                m.to_out[0].bias.copy_((0.01 * torch.randn(m.to_out[0].bias.shape, generator=g))
+                m.to_out[0].bias.copy_((0.01 * torch.randn(m.to_out[0].bias.shape, generator=g, device=gdev))
                                        .to(m.to_out[0].bias.dtype))
 
     @property

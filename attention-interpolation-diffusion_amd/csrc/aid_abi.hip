@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "aid_kernels.hpp"
 
 namespace {
@@ -16,6 +18,34 @@ int fail_hip(hipError_t e, const char* where) {
     snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
     return AID_ERR_LAUNCH;
 }
+
+// ---- live timing (aid_profile_begin / aid_profile_end) -------------------------------------------
+struct ProfRec {
+    hipEvent_t t0, t1;
+    char name[64];
+    double flops, bytes;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {          // records an event pair around one launch when profiling is on
+    hipStream_t stream;
+    bool on;
+    ProfScope(hipStream_t s, const char* name, double flops, double bytes) : stream(s), on(g_prof_on) {
+        if (!on) return;
+        ProfRec r;
+        hipEventCreate(&r.t0);
+        hipEventCreate(&r.t1);
+        snprintf(r.name, sizeof(r.name), "%s", name);
+        r.flops = flops;
+        r.bytes = bytes;
+        hipEventRecord(r.t0, stream);
+        g_prof.push_back(r);
+    }
+    ~ProfScope() {
+        if (on) hipEventRecord(g_prof.back().t1, stream);
+    }
+};
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -102,6 +132,36 @@ int aid_device_info(int* n_cu, int* clock_khz, char* arch) {
     return AID_OK;
 }
 
+int aid_profile_begin(void) {
+    for (auto& r : g_prof) { hipEventDestroy(r.t0); hipEventDestroy(r.t1); }
+    g_prof.clear();
+    g_prof_on = true;
+    return AID_OK;
+}
+
+int aid_profile_end(AidProfileEntry* entries, int max_entries) {
+    g_prof_on = false;
+    int n = 0;
+    int rc = AID_OK;
+    for (auto& r : g_prof) {
+        hipError_t e = hipEventSynchronize(r.t1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.t0, r.t1);
+        if (e != hipSuccess) rc = fail_hip(e, "aid_profile_end");
+        if (entries && n < max_entries && e == hipSuccess) {
+            memcpy(entries[n].kernel, r.name, sizeof(r.name));
+            entries[n].ms = ms;
+            entries[n].flops = r.flops;
+            entries[n].bytes = r.bytes;
+            ++n;
+        }
+        hipEventDestroy(r.t0);
+        hipEventDestroy(r.t1);
+    }
+    g_prof.clear();
+    return rc == AID_OK ? n : rc;
+}
+
 int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void* stream) {
     if (!problems || n_problems < 1 || n_problems > AID_GEMM_MAX_PROBLEMS) return AID_ERR_ARG;
     if (dtype != AID_DTYPE_F16 && dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
@@ -122,7 +182,21 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
         tiles += aid::gemm_tiles(q.m, q.n, q.batch);
     }
     for (int i = n_problems; i <= AID_GEMM_MAX_PROBLEMS; ++i) g.tile_start[i] = tiles;
-    hipError_t e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream));
+    double flops = 0, bytes = 0;
+    if (g_prof_on) {
+        for (int i = 0; i < n_problems; ++i) {
+            const AidGemmProblem& q = problems[i];
+            flops += 2.0 * q.m * q.n * q.k * q.batch;
+            bytes += 2.0 * ((double)q.m * q.k * (q.stride_a || q.batch == 1 ? q.batch : 1) +
+                            (double)q.n * q.k * (q.stride_b || q.batch == 1 ? q.batch : 1) + (double)q.m * q.n * q.batch);
+        }
+    }
+    hipError_t e;
+    {
+        ProfScope ps(static_cast<hipStream_t>(stream), dtype == AID_DTYPE_F16 ? "aid_gemm_nt<f16>" : "aid_gemm_nt<bf16>",
+                     flops, bytes);
+        e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream));
+    }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_gemm_nt");
 }
 
@@ -140,7 +214,18 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4 || a.ldvt < a.l) return AID_ERR_SHAPE;
     if (a.q_fs % 8 || a.k_fs % 8 || a.vt_fs % 8 || a.o_fs % 4) return AID_ERR_SHAPE;
     if (!aligned16(a.q) || !aligned16(a.k) || !aligned16(a.vt) || !aligned16(a.out)) return AID_ERR_SHAPE;
-    hipError_t e = aid::attn_launch(a, static_cast<hipStream_t>(stream), &g_variant);
+    // algorithmic work: key segments per frame — plain 1, pure inner 1, fused inner 2,
+    // pure outer 2, fused outer 3
+    const int segs = a.mode == AID_MODE_PLAIN ? 1 : (a.mode == AID_MODE_INNER ? 1 : 2) + (a.fused ? 1 : 0);
+    const double c = (double)a.heads * a.d;
+    const double flops = 4.0 * a.n_frames * a.s * ((double)segs * a.l) * c;
+    const double bytes = 2.0 * (2.0 * a.n_frames * a.s * c + 2.0 * a.n_kv * a.l * c);
+    hipError_t e;
+    {
+        const char* nm = aid::attn_variant_name(a);
+        ProfScope ps(static_cast<hipStream_t>(stream), nm, flops, bytes);
+        e = aid::attn_launch(a, static_cast<hipStream_t>(stream), &g_variant);
+    }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
 }
 

@@ -358,10 +358,12 @@ static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+static int attn_nw(const AidAttnArgs& a);
+
 template <typename T, int D, int MODE>
 static hipError_t launch_nw(AttnKParams& p, hipStream_t stream, int* nw_out) {
     // small images: one wave per workgroup so the grid still covers the 256 CUs
-    const int nw = (p.a.s * p.a.n_frames * p.a.heads >= 128 * 512) ? 4 : 1;
+    const int nw = attn_nw(p.a);
     *nw_out = nw;
     p.nqb = (p.a.s + 32 * nw - 1) / (32 * nw);
     return nw == 4 ? launch_variant<T, D, MODE, 4>(p, stream) : launch_variant<T, D, MODE, 1>(p, stream);
@@ -389,6 +391,16 @@ static hipError_t launch_d(AttnKParams& p, hipStream_t stream, int* nw_out) {
 
 bool attn_head_dim_supported(int d) { return d == 40 || d == 64 || d == 80 || d == 160; }
 
+static int attn_nw(const AidAttnArgs& a) { return ((int64_t)a.s * a.n_frames * a.heads >= 128 * 512) ? 4 : 1; }
+
+const char* attn_variant_name(const AidAttnArgs& a) {
+    static thread_local char name[64];
+    static const char* modes[] = {"plain", "inner", "outer"};
+    snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
+             modes[a.mode], attn_nw(a));
+    return name;
+}
+
 hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** variant) {
     AttnKParams p;
     p.a = a;
@@ -396,13 +408,7 @@ hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** va
     p.c2 = a.softmax_scale * 1.4426950408889634f;
     int nw = 0;
     hipError_t e = (a.dtype == AID_DTYPE_F16) ? launch_d<f16>(p, stream, &nw) : launch_d<bf16>(p, stream, &nw);
-    if (variant) {
-        static thread_local char name[64];
-        static const char* modes[] = {"plain", "inner", "outer"};
-        snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
-                 modes[a.mode], nw);
-        *variant = name;
-    }
+    if (variant) *variant = attn_variant_name(a);
     return e;
 }
 

@@ -28,5 +28,6 @@ hipError_t gemm_group_launch(const GemmGroup& g, int dtype, hipStream_t stream);
 // attention core; returns hipSuccess / error, writes the variant name for profiling
 hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** variant);
 bool       attn_head_dim_supported(int d);
+const char* attn_variant_name(const AidAttnArgs& a);   // thread-local buffer
 
 }  // namespace aid

@@ -1,0 +1,118 @@
+"""Denoising-loop harness around the AID processors (host orchestration rows of SURVEY.md §2).
+
+Mirrors the control flow of the reference loops:
+  * N-frame batch, one frame per coefficient — gradio ``interpolate``
+    (gradio_src/pipeline_interpolated_stable_diffusion.py:163-304);
+  * warm-up rule of the root pipelines — AID on for the CONDITIONAL pass of steps
+    ``i < int(num_inference_steps * warmup_ratio)`` (0-based), de-activated otherwise, and always
+    de-activated for the UNCONDITIONAL pass (pipeline_interpolated_sd.py:1831, 1845-1848, 1870;
+    SURVEY.md App. D1: the build follows root, not gradio's off-by-one);
+  * classifier-free guidance ``uncond + gs * (text - uncond)`` (pipeline_interpolated_sd.py:1892).
+The UNet is anything exposing diffusers' ``attn_processors`` / ``set_attn_processor`` and being
+callable as ``unet(sample, encoder_hidden_states)`` — a real diffusers UNet2DConditionModel wrapped
+by the caller, or :class:`AttnStackUNet` (attention calls only) in the benchmark.
+
+MI355X-first: the three distinct passes of the loop (conditional+AID, conditional plain,
+unconditional plain) are captured once into hipGraphs and replayed per step, so the 32 (SD1.5) /
+140 (SDXL) x 3 kernel launches of a pass cost one graph launch on the host.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from .processors import (HipAttnProcessor, InnerInterpolatedAttnProcessor, InterpolatedAttnProcessor,
+                         OuterInterpolatedAttnProcessor)
+
+EARLY_MODES = ("pure_inner", "fused_inner", "pure_outer", "fused_outer")
+
+
+def install_sequence_processors(unet, size: int, early: str = "fused_outer", alpha: Optional[float] = None,
+                                beta: Optional[float] = None, num_inference_steps: int = 50,
+                                coef: Optional[torch.Tensor] = None) -> None:
+    """One AID processor per attention layer for an N-frame sequence; Beta(alpha, beta) coefficients with
+    alpha = beta = num_inference_steps by default (gradio_src/...stable_diffusion.py:203-206, 237-260).
+    ``coef`` overrides the schedule (used by the frame-sharded layout: the local rows of the global
+    schedule)."""
+    if early not in EARLY_MODES:
+        raise ValueError(f"early must be one of {EARLY_MODES}")
+    alpha = num_inference_steps if alpha is None else alpha
+    beta = num_inference_steps if beta is None else beta
+    cls = OuterInterpolatedAttnProcessor if early.endswith("outer") else InnerInterpolatedAttnProcessor
+    procs = {}
+    for name in unet.attn_processors.keys():
+        p = cls(size=size, is_fused=early.startswith("fused"), alpha=alpha, beta=beta,
+                original_attn=HipAttnProcessor())
+        if coef is not None:
+            assert coef.numel() == size
+            p.coef = coef.detach().to(torch.float32).cpu().clone()
+        procs[name] = p
+    unet.set_attn_processor(procs)
+
+
+def set_aid_active(unet, active: bool) -> None:
+    """N-frame analogue of activate_aid / deactivate_aid that keeps the coefficient schedule
+    (the reference's activate(t) resets coef to [0, t, 1] for its batch-3 loop)."""
+    for proc in unet.attn_processors.values():
+        if isinstance(proc, InterpolatedAttnProcessor):
+            proc.activated = bool(active)
+
+
+class AidDenoiseLoop:
+    """Replays the per-step attention work of an interpolation run.
+
+    step(i): conditional pass (AID on while i < warmup_steps) + unconditional pass (plain) + CFG
+    combine of the two pass outputs.  ``use_graphs`` captures the passes into hipGraphs.
+    """
+
+    def __init__(self, unet, sample, cond, uncond, num_inference_steps: int = 50, warmup_ratio: float = 0.5,
+                 guidance_scale: float = 7.5, use_graphs: bool = True, combine: Optional[Callable] = None):
+        self.unet, self.sample, self.cond, self.uncond = unet, sample, cond, uncond
+        self.num_inference_steps = num_inference_steps
+        self.warmup_steps = int(num_inference_steps * warmup_ratio)        # pipeline_interpolated_sd.py:1831
+        self.guidance_scale = guidance_scale
+        self.use_graphs = use_graphs
+        self.combine = combine or self._cfg
+        self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self._outs: Dict[str, object] = {}
+
+    def _cfg(self, text, uncond):
+        if isinstance(text, dict):
+            return {k: uncond[k] + self.guidance_scale * (text[k] - uncond[k]) for k in text}
+        return uncond + self.guidance_scale * (text - uncond)
+
+    # -- the three distinct passes ---------------------------------------------------------------
+    def _pass(self, which: str):
+        if which == "cond_aid":
+            set_aid_active(self.unet, True)
+            return self.unet(self.sample, self.cond)
+        set_aid_active(self.unet, False)
+        return self.unet(self.sample, self.cond if which == "cond_plain" else self.uncond)
+
+    def _run(self, which: str):
+        if not self.use_graphs:
+            return self._pass(which)
+        g = self._graphs.get(which)
+        if g is None:
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):              # warm-up: lazy kernel attributes, coef caches, workspaces
+                self._pass(which)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._outs[which] = self._pass(which)
+            self._graphs[which] = g
+        g.replay()
+        return self._outs[which]
+
+    def aid_on(self, i: int) -> bool:
+        return i < self.warmup_steps
+
+    def step(self, i: int):
+        text = self._run("cond_aid" if self.aid_on(i) else "cond_plain")
+        unc = self._run("uncond")
+        return self.combine(text, unc)

@@ -150,6 +150,26 @@ typedef struct AidProcessorArgs {
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args /* host */);
 int    aid_processor_fwd(const AidProcessorArgs* args /* host */, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Live kernel timing (bench.py's roofline leg): between aid_profile_begin() and
+ * aid_profile_end() every kernel launched through this library is bracketed by a pair of
+ * HIP events recorded on the launch stream.  aid_profile_end() synchronises those events and
+ * returns one entry per launch: elapsed milliseconds plus the ALGORITHMIC work of the launch
+ * (flops: 2*m*n*k per GEMM problem, 4*s*l*c per (frame, key segment) of attention with the
+ * segment count of SURVEY.md §8d: plain 1, pure inner 1, fused inner 2, pure outer 2, fused
+ * outer 3; bytes: operands read once + result written once).  Not for use inside stream capture.
+ * ------------------------------------------------------------------------------------- */
+typedef struct AidProfileEntry {
+    char   kernel[64];     /* variant name, e.g. "aid_attn<f16,d40,inner,nw4>" or "aid_gemm_nt<f16>" */
+    double ms;
+    double flops;
+    double bytes;
+} AidProfileEntry;
+
+int aid_profile_begin(void);
+/* returns the number of entries written (<= max_entries) or a negative error code */
+int aid_profile_end(AidProfileEntry* entries /* host */, int max_entries);
+
 /* misc */
 int         aid_abi_version(void);
 const char* aid_strerror(int code);

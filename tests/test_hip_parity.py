@@ -1,0 +1,316 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the oracle and the committed goldens.
+Run on the MI355X box with ``pytest -m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+from oracle import aid_oracle as O
+from util import TOL, TOL_GEMM, make_attn, rel_l2, rounded, to_np64
+
+pytestmark = pytest.mark.gpu
+
+import aid_amd  # noqa: E402
+from aid_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+DTYPES = [torch.float16, torch.bfloat16]
+ids_dt = lambda d: str(d).split(".")[-1]  # noqa: E731
+
+
+def test_native_library_is_what_runs():
+    lib = aid_amd._lib.load()
+    import ctypes
+    ncu, clk, arch = ctypes.c_int(), ctypes.c_int(), ctypes.create_string_buffer(32)
+    assert lib.aid_device_info(ctypes.byref(ncu), ctypes.byref(clk), arch) == 0
+    assert arch.value.decode().startswith("gfx950"), arch.value
+    assert ncu.value == 256
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("mnk", [(1, 8, 8), (129, 320, 320), (231, 640, 768), (1000, 1280, 2048), (4096, 640, 640),
+                                 (257, 324, 72)])
+def test_gemm_nt_vs_fp64(dtype, mnk):
+    m, n, k = mnk
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    a = torch.randn(m, k, generator=g).to(dtype)
+    b = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype)
+    bias = torch.randn(n, generator=g).to(dtype)
+    ref = to_np64(a) @ to_np64(b).T
+    y = ops.linear(a.to(DEV), b.to(DEV))
+    assert rel_l2(to_np64(y), ref) < TOL_GEMM[dtype]
+    yb = ops.linear(a.to(DEV), b.to(DEV), bias.to(DEV))
+    assert rel_l2(to_np64(yb), ref + to_np64(bias)) < TOL_GEMM[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("shape", [(3, 77, 96, 80), (7, 200, 64, 128), (2, 5, 8, 40)])
+def test_kv_projection_writes_transposed_values_and_zero_padding(dtype, shape):
+    f, l, cc, c = shape
+    g = torch.Generator().manual_seed(l)
+    e = torch.randn(f, l, cc, generator=g).to(dtype)
+    wk = (torch.randn(c, cc, generator=g) / cc ** 0.5).to(dtype)
+    wv = (torch.randn(c, cc, generator=g) / cc ** 0.5).to(dtype)
+    k, vt = ops.project_kv(e.to(DEV), wk.to(DEV), wv.to(DEV))
+    assert vt.shape == (f, c, (l + 7) // 8 * 8)
+    assert rel_l2(to_np64(k), to_np64(e) @ to_np64(wk).T) < TOL_GEMM[dtype]
+    assert rel_l2(to_np64(vt[:, :, :l]), (to_np64(e) @ to_np64(wv).T).transpose(0, 2, 1)) < TOL_GEMM[dtype]
+    lp4 = (l + 3) // 4 * 4
+    assert float(vt[:, :, l:lp4].abs().max()) == 0.0 if lp4 > l else True
+
+
+# ------------------------------------------------------------------------------------------------
+# attention core vs oracle
+# ------------------------------------------------------------------------------------------------
+def _core_inputs(n, s, l, h, d, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    c = h * d
+    q = torch.randn(n, s, c, generator=g).to(dtype)
+    k = torch.randn(n, l, c, generator=g).to(dtype)
+    v = torch.randn(n, l, c, generator=g).to(dtype)
+    lp = (l + 7) // 8 * 8
+    vt = torch.zeros(n, c, lp, dtype=dtype)
+    vt[:, :, :l] = v.transpose(1, 2)
+    return q, k, v, vt
+
+
+def _coef(n):
+    return torch.tensor([0.0, 0.3, 1.0]) if n == 3 else torch.from_numpy(O.beta_coefs(n, 3, 3))
+
+
+MODES = [("plain", False), ("inner", False), ("inner", True), ("outer", False), ("outer", True)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("d", [40, 64, 80, 160])
+@pytest.mark.parametrize("shape", [(3, 40, 77, 2), (7, 200, 200, 2), (3, 33, 130, 1), (5, 1, 1, 2), (3, 700, 64, 8)],
+                         ids=lambda s: "n%d_s%d_l%d_h%d" % s)
+def test_attention_core_all_modes(dtype, d, shape):
+    n, s, l, h = shape
+    q, k, v, vt = _core_inputs(n, s, l, h, d, dtype, seed=d * 1000 + s)
+    coef = _coef(n)
+    for mode, fused in MODES:
+        o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused, coef=coef.to(DEV))
+        ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, mode, fused, coef.numpy())
+        err = rel_l2(to_np64(o), ref)
+        assert err < TOL[dtype], (mode, fused, ops.last_attn_variant(), err)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+def test_attention_core_sharded_endpoints_accumulate_and_maps(dtype):
+    """begin/end != (0, N-1), kv_map, frame_scale, out_scale and accumulate (what the IP processors and
+    the frame-sharded multi-GPU layout use)."""
+    n, s, l, h, d = 4, 96, 50, 2, 64
+    q, k, v, vt = _core_inputs(n, s, l, h, d, dtype, seed=5)
+    coef = torch.tensor([0.2, 0.0, 1.0, 0.7])
+    o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="outer", fused=True, coef=coef.to(DEV),
+                     begin=1, end=2)
+    ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, "outer", True, coef.numpy(), begin=1, end=2)
+    assert rel_l2(to_np64(o), ref) < TOL[dtype]
+    # kv_map: frames 0..3 use kv rows [2, 0, 0, 1]
+    kv_map = torch.tensor([2, 0, 0, 1], dtype=torch.int32)
+    o2 = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="plain", kv_map=kv_map.to(DEV))
+    ref2 = O.attn_core(to_np64(q), to_np64(k)[kv_map.numpy()], to_np64(v)[kv_map.numpy()], h, d ** -0.5, "plain",
+                       False, None)
+    assert rel_l2(to_np64(o2), ref2) < TOL[dtype]
+    # accumulate with out_scale and per-frame scale on top of an existing tensor
+    base = torch.randn(n, s, h * d).to(dtype)
+    fs = torch.tensor([0.5, 0.0, 1.0, 2.0])
+    o3 = base.clone().to(DEV)
+    ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="plain", out=o3, accumulate=True, out_scale=0.6,
+                 frame_scale=fs.to(DEV))
+    plain = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, "plain", False, None)
+    ref3 = to_np64(base) + 0.6 * fs.numpy().reshape(-1, 1, 1) * plain
+    assert rel_l2(to_np64(o3), ref3) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+def test_online_softmax_rescale_is_exercised(dtype):
+    """Force the running-max update late in the key sequence (a spiked key in the last tile and one in
+    the middle) — the data-dependent rescale branch never fires on bounded random data."""
+    n, s, l, h, d = 3, 64, 300, 1, 64
+    q, k, v, vt = _core_inputs(n, s, l, h, d, dtype, seed=11)
+    k[:, 150] = q[:, 3] * 4.0          # large score for query 3 in tile 2
+    k[:, 299] = q[:, 7] * 6.0          # even larger for query 7 in the last tile
+    for mode, fused in MODES:
+        o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused, coef=_coef(n).to(DEV))
+        ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, mode, fused, _coef(n).numpy())
+        assert np.isfinite(to_np64(o)).all()
+        assert rel_l2(to_np64(o), ref) < TOL[dtype], (mode, fused)
+
+
+def test_outer_equals_inner_when_endpoints_coincide():
+    """If K/V of the two end-point frames are identical every mode collapses to attention against
+    [own;] that frame."""
+    dtype = torch.float16
+    n, s, l, h, d = 4, 80, 90, 2, 40
+    q, k, v, vt = _core_inputs(n, s, l, h, d, dtype, seed=3)
+    k[-1], v[-1], vt[-1] = k[0], v[0], vt[0]
+    coef = torch.tensor([0.0, 0.25, 0.6, 1.0]).to(DEV)
+    for fused in (False, True):
+        oo = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="outer", fused=fused, coef=coef)
+        oi = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="inner", fused=fused, coef=coef)
+        assert rel_l2(to_np64(oo), to_np64(oi)) < 1.5e-3
+
+
+def test_bitwise_deterministic():
+    q, k, v, vt = _core_inputs(7, 512, 512, 4, 64, torch.bfloat16, seed=1)
+    coef = _coef(7).to(DEV)
+    a = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), 4, l=512, mode="outer", fused=True, coef=coef)
+    b = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), 4, l=512, mode="outer", fused=True, coef=coef)
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole processor calls vs the committed goldens (reference outputs) and the oracle
+# ------------------------------------------------------------------------------------------------
+TEXT = C.load_fixture("text_goldens.npz")
+IPG = C.load_fixture("ip_goldens.npz")
+
+
+def _text_proc(case):
+    if case.mode == "plain":
+        return aid_amd.HipAttnProcessor()
+    cls = aid_amd.OuterInterpolatedAttnProcessor if case.mode.endswith("outer") else aid_amd.InnerInterpolatedAttnProcessor
+    return cls(t=case.t, size=case.n, is_fused=case.mode.startswith("fused"), alpha=case.alpha, beta=case.beta)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("case", C.TEXT_CASES, ids=lambda c: c.name)
+def test_text_processors_vs_reference_goldens(case, dtype):
+    inp = C.text_inputs(case)
+    attn = make_attn(aid_amd, inp, case.heads, case.cc if case.cross else None, dtype, DEV)
+    x = torch.from_numpy(inp["x"]).to(dtype).to(DEV)
+    ctx = torch.from_numpy(inp["ctx"]).to(dtype).to(DEV) if case.cross else None
+    y = _text_proc(case)(attn, x, encoder_hidden_states=ctx)
+    assert y.shape == x.shape and y.dtype == dtype
+    # (1) against the reference's fp32 output on the un-rounded inputs (includes input rounding)
+    assert rel_l2(to_np64(y), TEXT[case.name]) < TOL[dtype]
+    # (2) against the oracle in fp64 on the SAME rounded inputs
+    r = rounded(inp, dtype)
+    w = O.AttnWeights(r["wq"], r["wk"], r["wv"], r["wo"], r["bo"], case.heads)
+    if case.mode == "plain":
+        ref = O.plain_attention(r["x"], r.get("ctx"), w)
+    else:
+        coef = torch.from_numpy(TEXT[case.name + "__coef"]).to(dtype).float().numpy()
+        fn = O.outer_attention if case.mode.endswith("outer") else O.inner_attention
+        ref = fn(r["x"], r.get("ctx"), w, coef, case.mode.startswith("fused"))
+    assert rel_l2(to_np64(y), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("case", C.IP_CASES, ids=lambda c: c.name)
+def test_ip_processors_vs_reference_goldens(case, dtype):
+    inp = C.ip_inputs(case)
+    attn = make_attn(aid_amd, inp, case.heads, case.cc, dtype, DEV)
+    ipa = aid_amd.IPAdapterShim(case.c, case.cc, num_tokens=case.tokens, scale=case.ip_scale, dtype=dtype, device=DEV)
+    with torch.no_grad():
+        ipa.to_k_ip[0].weight.copy_(torch.from_numpy(inp["wk_ip"]).to(dtype))
+        ipa.to_v_ip[0].weight.copy_(torch.from_numpy(inp["wv_ip"]).to(dtype))
+    cls = {"outer_ip": aid_amd.OuterInterpolatedIPAttnProcessor, "inner_ip": aid_amd.InnerInterpolatedIPAttnProcessor,
+           "scale_control": aid_amd.ScaleControlIPAttnProcessor,
+           "scale_control_off": aid_amd.ScaleControlIPAttnProcessor}[case.kind]
+    proc = cls(t=case.t, is_fused=case.is_fused, ip_attn=ipa)
+    if case.kind == "scale_control_off":
+        proc.deactivate()
+    ehs = (torch.from_numpy(inp["text"]).to(dtype).to(DEV), [torch.from_numpy(inp["ip"]).to(dtype).to(DEV)])
+    y = proc(attn, torch.from_numpy(inp["x"]).to(dtype).to(DEV), encoder_hidden_states=ehs)
+    assert rel_l2(to_np64(y), IPG[case.name]) < TOL[dtype]
+
+
+def test_inner_ip_without_fusion_raises_like_reference():
+    case = C.IPCase("x", "inner_ip", False, 4)
+    inp = C.ip_inputs(case)
+    dtype = torch.float16
+    attn = make_attn(aid_amd, inp, case.heads, case.cc, dtype, DEV)
+    ipa = aid_amd.IPAdapterShim(case.c, case.cc, num_tokens=4, dtype=dtype, device=DEV)
+    proc = aid_amd.InnerInterpolatedIPAttnProcessor(t=0.3, is_fused=False, ip_attn=ipa)
+    ehs = (torch.from_numpy(inp["text"]).to(dtype).to(DEV), [torch.from_numpy(inp["ip"]).to(dtype).to(DEV)])
+    with pytest.raises(RuntimeError):
+        proc(attn, torch.from_numpy(inp["x"]).to(dtype).to(DEV), encoder_hidden_states=ehs)
+
+
+def test_error_behaviour_batch_mismatch_dtype_and_mask():
+    attn = aid_amd.AttnShim(80, 2, dtype=torch.float16, device=DEV)
+    proc = aid_amd.OuterInterpolatedAttnProcessor(size=7, is_fused=True)
+    with pytest.raises(RuntimeError, match="must match the size"):        # reference: broadcast error at the lerp
+        proc(attn, torch.randn(5, 16, 80, dtype=torch.float16, device=DEV))
+    attn32 = aid_amd.AttnShim(80, 2, dtype=torch.float32, device=DEV)
+    with pytest.raises(TypeError, match="float16 / bfloat16"):
+        aid_amd.HipAttnProcessor()(attn32, torch.randn(3, 16, 80, device=DEV))
+    with pytest.raises(NotImplementedError):
+        aid_amd.HipAttnProcessor()(attn, torch.randn(3, 16, 80, dtype=torch.float16, device=DEV),
+                                   attention_mask=torch.zeros(3, 1, 16, device=DEV))
+    attn_bad = aid_amd.AttnShim(96, 2, dtype=torch.float16, device=DEV)   # head dim 48 unsupported
+    with pytest.raises(RuntimeError, match="head dim"):
+        aid_amd.HipAttnProcessor()(attn_bad, torch.randn(3, 16, 96, dtype=torch.float16, device=DEV))
+
+
+def test_deactivated_processor_delegates_or_runs_plain():
+    dtype = torch.float16
+    case = C.TEXT_CASES[0]
+    inp = C.text_inputs(case)
+    attn = make_attn(aid_amd, inp, case.heads, None, dtype, DEV)
+    x = torch.from_numpy(inp["x"]).to(dtype).to(DEV)
+    plain = aid_amd.HipAttnProcessor()(attn, x)
+    calls = []
+
+    def original(attn_, hs, ehs, mask, temb):
+        calls.append(1)
+        return hs * 2
+    p = aid_amd.InnerInterpolatedAttnProcessor(t=0.5, is_fused=True, original_attn=original)
+    p.deactivate()
+    assert torch.equal(p(attn, x), x * 2) and calls == [1]
+    p2 = aid_amd.InnerInterpolatedAttnProcessor(t=0.5, is_fused=True)
+    p2.deactivate()
+    assert torch.equal(p2(attn, x), plain)
+    p2.activate(0.5)
+    assert not torch.equal(p2(attn, x), plain)
+
+
+def test_4d_input_residual_and_rescale_branches():
+    """interpolation.py:593-597 / 669-677 (dead for UNet calls, kept for parity)."""
+    dtype = torch.float16
+    attn = aid_amd.AttnShim(80, 2, dtype=dtype, device=DEV)
+    x4 = torch.randn(3, 80, 4, 6, dtype=dtype, device=DEV)
+    proc = aid_amd.OuterInterpolatedAttnProcessor(t=0.4, is_fused=True)
+    y3 = proc(attn, x4.view(3, 80, 24).transpose(1, 2).contiguous())
+    attn.residual_connection, attn.rescale_output_factor = True, 2.0
+    y4 = proc(attn, x4)
+    want = (y3.transpose(-1, -2).reshape(3, 80, 4, 6) + x4) / 2.0
+    assert y4.shape == x4.shape and rel_l2(to_np64(y4), to_np64(want)) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE sizes: size-independent properties (the oracle would take minutes here)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model,dtype", [("sd15", torch.float16), ("sdxl", torch.bfloat16)])
+def test_full_size_layer_properties(model, dtype):
+    """SD1.5 (S=4096, C=320, H=8, d=40) / SDXL (S=4096, C=640, H=10, d=64), N=7:
+    (a) end-point frames of every fused mode equal plain attention of that frame,
+    (b) a sampled set of query rows matches the fp64 oracle, (c) linearity in V."""
+    s, c, h = (4096, 320, 8) if model == "sd15" else (4096, 640, 10)
+    n, d = 7, c // h
+    g = torch.Generator().manual_seed(1002)
+    q = torch.randn(n, s, c, generator=g).to(dtype).to(DEV)
+    k = torch.randn(n, s, c, generator=g).to(dtype).to(DEV)
+    v = torch.randn(n, s, c, generator=g).to(dtype).to(DEV)
+    vt = v.transpose(1, 2).contiguous()
+    coef = torch.from_numpy(O.beta_coefs(n, 50, 50)).to(DEV)
+    plain = ops.attn_fwd(q, k, vt, h, l=s, mode="plain")
+    rows = torch.tensor([0, 31, 32, 1000, 2047, 4095])
+    for mode in ("inner", "outer"):
+        o = ops.attn_fwd(q, k, vt, h, l=s, mode=mode, fused=True, coef=coef)
+        assert rel_l2(to_np64(o[[0, n - 1]]), to_np64(plain[[0, n - 1]])) < TOL[dtype]          # (a)
+        assert rel_l2(to_np64(o[3]), to_np64(plain[3])) > 10 * TOL[dtype]
+        qs = q[:, rows].contiguous()
+        ref = O.attn_core(to_np64(qs), to_np64(k), to_np64(v), h, d ** -0.5, mode, True, coef.cpu().numpy())
+        assert rel_l2(to_np64(o[:, rows]), ref) < TOL[dtype]                                      # (b)
+    v2 = torch.randn(n, s, c, generator=g).to(dtype).to(DEV)
+    o1 = ops.attn_fwd(q, k, vt, h, l=s, mode="outer", fused=True, coef=coef)
+    o2 = ops.attn_fwd(q, k, v2.transpose(1, 2).contiguous(), h, l=s, mode="outer", fused=True, coef=coef)
+    o12 = ops.attn_fwd(q, k, (v + v2).transpose(1, 2).contiguous(), h, l=s, mode="outer", fused=True, coef=coef)
+    assert rel_l2(to_np64(o12), to_np64(o1) + to_np64(o2)) < 2 * TOL[dtype]                      # (c)

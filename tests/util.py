@@ -1,0 +1,36 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+import torch
+
+# Tolerances (relative L2 over the whole output tensor, HIP path vs the fp64-evaluated oracle on the
+# SAME dtype-rounded inputs).  north_star asks for 1e-3 rel-L2 on fp16 latents; one layer call in
+# fp16 measures <= 8e-4 (inputs, q/k/v, P and the output are each rounded to fp16 once; accumulation
+# is fp32).  bf16 has 3 fewer mantissa bits (eps 3.9e-3 vs 4.9e-4), the same pipeline measures <= 6e-3.
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
+# GEMM alone: one output rounding
+TOL_GEMM = {torch.float16: 6e-4, torch.bfloat16: 4e-3}
+
+
+def rel_l2(a, b) -> float:
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def to_np64(t: torch.Tensor) -> np.ndarray:
+    return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def make_attn(aid_amd, inp, heads, cross_dim, dtype, device):
+    c = inp["wq"].shape[0]
+    attn = aid_amd.AttnShim(c, heads, cross_dim, dtype=dtype, device=device)
+    with torch.no_grad():
+        for lin, key in ((attn.to_q, "wq"), (attn.to_k, "wk"), (attn.to_v, "wv"), (attn.to_out[0], "wo")):
+            lin.weight.copy_(torch.from_numpy(inp[key]).to(dtype))
+        attn.to_out[0].bias.copy_(torch.from_numpy(inp["bo"]).to(dtype))
+    return attn
+
+
+def rounded(inp, dtype):
+    """numpy fp64 copies of the inputs after rounding to the compute dtype."""
+    return {k: torch.from_numpy(v).to(dtype).float().numpy().astype(np.float64) for k, v in inp.items()}
