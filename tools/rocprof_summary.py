@@ -17,12 +17,12 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     lines = [f"# rocprofv3 --kernel-trace --stats   source: {sys.argv[1]}",
-             f"{'calls':>8} {'total_us':>14} {'avg_us':>10} {'pct':>7}  kernel"]
+             f"{'calls':>8} {'total_ms':>14} {'avg_us':>10} {'pct':>7}  kernel"]
     for name, calls, tot, avg, pct in rows:
         nm = demangle(name).replace("aid::", "")
         if len(nm) > 110:
             nm = nm[:107] + "..."
-        lines.append(f"{calls:8d} {tot/1e3:14.1f} {avg/1e3:10.2f} {pct:7.2f}  {nm}")
+        lines.append(f"{calls:8d} {tot/1e3:14.2f} {avg:10.2f} {pct:7.2f}  {nm}")
     txt = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(txt)
