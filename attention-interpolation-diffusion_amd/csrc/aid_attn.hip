@@ -19,13 +19,21 @@
 //   The K tile is read with key bits 2<->3 swapped so the P registers a lane holds after the first
 //   product are exactly the 8 consecutive keys it must supply as B operand to the second one
 //   (no cross-lane shuffle of P).
+// Online softmax in the base-2 domain with a LAZY rescale: the running reference m of a row is only
+// raised (and O, l rescaled) when some row of the wave saw a score more than 2^8 above its
+// reference; otherwise P = 2^(s - m) simply exceeds 1 (<= 256, exact in fp16/bf16/fp32 floating
+// point), which removes the 32-accumulator rescale from almost every tile.  The decision is
+// wave-uniform and taken before the tile's P is formed.
 // K / Vt tiles go global -> registers -> LDS (issued before the tile's compute, written after it,
-// two LDS buffers, one barrier per tile); INNER lerps the two end-point tiles in registers on the
-// way (the interpolated K/V never exist in HBM).  LDS rows are padded by 16 B (odd 16-B stride) so
-// all fragment reads are bank-conflict free.
+// two LDS buffers, one barrier per tile); the loads are branch-free (edge rows are clamped, never
+// predicated) and INNER lerps the two end-point tiles in registers on the way (the interpolated K/V
+// never exist in HBM).  LDS rows are padded by 16 B (odd 16-B stride): all fragment reads are
+// bank-conflict free.
 // OUTER shares the own-keys segment between its two softmaxes (3 segment passes, not 4): the online
 // state after the own segment is snapshotted and continued once with the begin and once with the
 // end frame; frames with coefficient exactly 0 / 1 skip the zero-weighted side.
+#include <type_traits>
+
 #include "aid_common.hpp"
 #include "aid_kernels.hpp"
 
@@ -33,6 +41,7 @@ namespace aid {
 
 constexpr int KT = 64;                  // keys per tile
 constexpr int VLD = KT + 8;             // padded Vt tile row (elements)
+constexpr float LAZY_TAU = 8.0f;        // log2 head-room before a row's reference max is raised
 
 struct AttnKParams {
     AidAttnArgs a;
@@ -48,6 +57,18 @@ struct OState {
     f32x16 o[NDB];
 };
 
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+__device__ __forceinline__ Rsrc make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
 template <typename T, int D, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) {
     typedef typename Vec<T>::v8 T8;
@@ -58,8 +79,9 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     constexpr int NQK = DK / 16, NDB = DV / 32;
     constexpr int NT = NW * 64;
     constexpr int DC = D / 8;                   // 16-B chunks per K row
-    constexpr int NKC = (KT * DC + NT - 1) / NT;        // K chunks per thread per tile
-    constexpr int NVC = (D * (KT / 8) + NT - 1) / NT;   // Vt chunks per thread per tile
+    constexpr int KCH = KT * DC, VCH = D * (KT / 8);    // chunks per K / Vt tile
+    constexpr int NKC = (KCH + NT - 1) / NT;    // K chunks per thread per tile
+    constexpr int NVC = (VCH + NT - 1) / NT;    // Vt chunks per thread per tile
     // Prefetch (issue tile t+1's loads before tile t's compute, two LDS buffers) only where the staging
     // registers fit beside the accumulators; otherwise stage synchronously through one buffer.
     constexpr bool PREFETCH = attn_prefetch(D, NW);
@@ -88,12 +110,12 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     // ---- Q fragments (B operand of the swapped product), straight from global -------------
     T8 qf[NQK];
     {
-        const T* qrow = reinterpret_cast<const T*>(a.q) + (int64_t)fr * a.q_fs + (int64_t)(q0 + l31) * a.ldq + h * D;
-        const bool rowok = (q0 + l31) < a.s;
+        const int qr = min(q0 + l31, a.s - 1);           // rows past the end are clamped, never stored
+        const T* qrow = reinterpret_cast<const T*>(a.q) + (int64_t)fr * a.q_fs + (int64_t)qr * a.ldq + h * D;
 #pragma unroll
         for (int ks = 0; ks < NQK; ++ks) {
             const int col = ks * 16 + hi * 8;
-            qf[ks] = (rowok && col < D) ? *reinterpret_cast<const T8*>(qrow + col) : zero8<T>();
+            qf[ks] = (col < D) ? *reinterpret_cast<const T8*>(qrow + col) : zero8<T>();
         }
     }
     __syncthreads();
@@ -103,31 +125,56 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const T* Kg = reinterpret_cast<const T*>(a.k) + h * D;
     const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)(h * D) * a.ldvt;
     const int L = a.l;
+    const int Lc8 = ((L - 1) >> 3) << 3;                // first key of the last 8-key chunk holding a valid key
     const float c2 = p.c2;
+    // key bits 2<->3 swapped: MFMA row i of the score block reads LDS key row pi(i)
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+
+    // per-lane byte offsets of this thread's staging chunks inside a full K / Vt tile
+    int kvo[NKC], vvo[NVC];
+#pragma unroll
+    for (int i = 0; i < NKC; ++i) {
+        const int id = min(tid + i * NT, KCH - 1);
+        kvo[i] = (id / DC) * (a.ldk * 2) + (id % DC) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NVC; ++i) {
+        const int id = min(tid + i * NT, VCH - 1);
+        vvo[i] = (id / (KT / 8)) * (a.ldvt * 2) + (id % (KT / 8)) * 16;
+    }
 
     // ---- one segment of keys: online-softmax update of `st` ----------------------------------
     // k0/v0: frame base pointers (already offset to head h); k1/v1 + c: lerp partner (INNER).
     auto run = [&](OState<NDB>& st, const T* k0, const T* v0, const T* k1, const T* v1, const bool lerp,
                    const float c) __attribute__((always_inline)) {
         T8 rk[NKC], rv[NVC], rk1[NKC], rv1[NVC];
-        auto stage_load = [&](int key0) __attribute__((always_inline)) {
+        // buffer descriptors of the segment's K / Vt (wave-uniform); per-lane byte offsets are 32-bit and the
+        // tile advance goes into the scalar offset, so a full tile costs no address VALU at all
+        const Rsrc sk0 = make_rsrc(k0), sv0 = make_rsrc(v0);
+        const Rsrc sk1 = make_rsrc(lerp ? k1 : k0), sv1 = make_rsrc(lerp ? v1 : v0);
+        auto stage_load = [&](int key0, auto full_tag) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
             for (int i = 0; i < NKC; ++i) {
-                const int id = tid + i * NT;
-                const int row = id / DC, cc = id % DC;
-                const bool ok = (id < KT * DC) && (key0 + row) < L;
-                const int64_t off = (int64_t)(key0 + row) * a.ldk + cc * 8;
-                rk[i] = ok ? *reinterpret_cast<const T8*>(k0 + off) : zero8<T>();
-                if (lerp) rk1[i] = ok ? *reinterpret_cast<const T8*>(k1 + off) : zero8<T>();
+                int vo = kvo[i], so = key0 * a.ldk * 2;
+                if (!FULL) {                            // ragged tile: clamp rows past the last key (never predicate)
+                    const int id = min(tid + i * NT, KCH - 1);
+                    vo = min(key0 + id / DC, L - 1) * (a.ldk * 2) + (id % DC) * 16;
+                    so = 0;
+                }
+                rk[i] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sk0, vo, so, 0));
+                if (lerp) rk1[i] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sk1, vo, so, 0));
             }
 #pragma unroll
             for (int i = 0; i < NVC; ++i) {
-                const int id = tid + i * NT;
-                const int row = id / (KT / 8), kc = key0 + (id % (KT / 8)) * 8;
-                const bool ok = (id < D * (KT / 8)) && kc < a.ldvt && kc < L;
-                const int64_t off = (int64_t)row * a.ldvt + kc;
-                rv[i] = ok ? *reinterpret_cast<const T8*>(v0 + off) : zero8<T>();
-                if (lerp) rv1[i] = ok ? *reinterpret_cast<const T8*>(v1 + off) : zero8<T>();
+                int vo = vvo[i], so = key0 * 2;
+                if (!FULL) {
+                    const int id = min(tid + i * NT, VCH - 1);
+                    vo = (id / (KT / 8)) * (a.ldvt * 2) + min(key0 + (id % (KT / 8)) * 8, Lc8) * 2;
+                    so = 0;
+                }
+                rv[i] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sv0, vo, so, 0));
+                if (lerp) rv1[i] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sv1, vo, so, 0));
             }
         };
         auto stage_write = [&](int buf, int key0) __attribute__((always_inline)) {
@@ -136,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 #pragma unroll
             for (int i = 0; i < NKC; ++i) {
                 const int id = tid + i * NT;
-                if (id >= KT * DC) continue;
+                if (NKC * NT != KCH && id >= KCH) continue;
                 T8 v = rk[i];
                 if (lerp) {
                     const f32x8 x0 = up8<T>(rk[i]), x1 = up8<T>(rk1[i]);
@@ -147,11 +194,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 }
                 *reinterpret_cast<T8*>(ks + (id / DC) * KLD + (id % DC) * 8) = v;
             }
+            const bool tail = key0 + KT > L;            // wave-uniform: the tile holds keys past the end
 #pragma unroll
             for (int i = 0; i < NVC; ++i) {
                 const int id = tid + i * NT;
-                if (id >= D * (KT / 8)) continue;
-                const int kc = key0 + (id % (KT / 8)) * 8;
+                if (NVC * NT != VCH && id >= VCH) continue;
                 T8 v = rv[i];
                 if (lerp) {
                     const f32x8 x0 = up8<T>(rv[i]), x1 = up8<T>(rv1[i]);
@@ -160,7 +207,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     for (int e = 0; e < 8; ++e) y[e] = fmaf(c, x1[e], (1.f - c) * x0[e]);
                     v = cvt8<T>(y);
                 }
-                if (kc + 8 > L) {                                   // chunk straddles the end of the keys
+                if (tail) {                             // keys >= L get P = 0; their V must be finite
+                    const int kc = min(key0 + (id % (KT / 8)) * 8, Lc8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if (kc + e >= L) v[e] = (T)0.0f;
@@ -169,63 +217,53 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             }
         };
 
-        const int nt = (L + KT - 1) / KT;
-        if (PREFETCH) {
-            stage_load(0);
-            stage_write(0, 0);
-            __syncthreads();
-        }
-        // key bits 2<->3 swapped: MFMA row i of the score block reads LDS key row pi(i)
-        const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-
-        for (int t = 0; t < nt; ++t) {
-            const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
-            if (PREFETCH) {
-                if (t + 1 < nt) stage_load(key0 + KT);
-            } else {
-                stage_load(key0);
-                stage_write(0, key0);
-                __syncthreads();
-            }
-            const int nb = (L - key0 > 32) ? 2 : 1;               // 32-key blocks with any valid key
-
-            // ---- S^T = K Q^T ------------------------------------------------------------------
+        // ---- compute on one staged tile; FULL = all 64 keys valid ---------------------------------
+        auto tile = [&](int buf, int key0, auto full_tag) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const int nb = FULL ? 2 : ((L - key0 > 32) ? 2 : 1);   // 32-key blocks with any valid key
+            // S^T = K Q^T
             f32x16 sc[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[b][r] = 0.f;
             const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                if (b < nb) {
+                if (FULL || b < nb) {
+                    sc[b] = mfma32(*reinterpret_cast<const T8*>(kt + b * 32 * KLD), qf[0], zero16());
 #pragma unroll
-                    for (int ks = 0; ks < NQK; ++ks) {
-                        const T8 ka = *reinterpret_cast<const T8*>(kt + b * 32 * KLD + ks * 16);
-                        sc[b] = mfma32(ka, qf[ks], sc[b]);
-                    }
+                    for (int ks = 1; ks < NQK; ++ks)
+                        sc[b] = mfma32(*reinterpret_cast<const T8*>(kt + b * 32 * KLD + ks * 16), qf[ks], sc[b]);
+                } else {
+                    sc[b] = zero16();
                 }
             }
             // lane (q, hi): sc[b][r] is the score of key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
-            if (key0 + KT > L) {
+            if (!FULL) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (key0 + 32 * b + 16 * (r >> 3) + 8 * hi + (r & 7) >= L) sc[b][r] = -INFINITY;
+                        if (key0 + 32 * b + 16 * (r >> 3) + 8 * hi + (r & 7) >= L) sc[b][r] = -1e30f;
             }
-            // ---- online softmax (base-2 domain) --------------------------------------------------
-            float tmax = sc[0][0];
+            // row max of the tile (in-lane tree + partner half)
+            float mx[8];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[b][r]);
+            for (int i = 0; i < 8; ++i)
+                mx[i] = fmaxf(fmaxf(sc[i >> 2][(i & 3) * 4], sc[i >> 2][(i & 3) * 4 + 1]),
+                              fmaxf(sc[i >> 2][(i & 3) * 4 + 2], sc[i >> 2][(i & 3) * 4 + 3]));
+            float tmax = fmaxf(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])), fmaxf(fmaxf(mx[4], mx[5]), fmaxf(mx[6], mx[7])));
             tmax = max_halves(tmax);
-            const float m_new = fmaxf(st.m, tmax);
-            const float alpha = __builtin_amdgcn_exp2f((st.m - m_new) * c2);
-            const float mc = m_new * c2;
-            st.m = m_new;
-            float psum = 0.f;
+            // lazy rescale: raise the reference only when some row of the wave out-grew its head-room
+            if (__any((tmax - st.m) * c2 > LAZY_TAU)) {
+                const float m_new = fmaxf(st.m, tmax);
+                const float alpha = __builtin_amdgcn_exp2f((st.m - m_new) * c2);
+                st.m = m_new;
+                st.l *= alpha;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st.o[d][r] *= alpha;
+            }
+            const float mc = st.m * c2;
+            float ps0 = 0.f, ps1 = 0.f;
             T8 pf[4];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -233,31 +271,55 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 for (int u = 0; u < 2; ++u) {
                     f32x8 pv;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pv[e] = __builtin_amdgcn_exp2f(fmaf(sc[b][8 * u + e], c2, -mc));
-                        psum += pv[e];
-                    }
+                    for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(fmaf(sc[b][8 * u + e], c2, -mc));
+                    ps0 += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                    ps1 += (pv[4] + pv[5]) + (pv[6] + pv[7]);
                     pf[2 * b + u] = cvt8<T>(pv);
                 }
-            st.l = st.l * alpha + psum;
-#pragma unroll
-            for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st.o[d][r] *= alpha;
-
-            // ---- O^T += Vt P^T --------------------------------------------------------------------
+            st.l += ps0 + ps1;
+            // O^T += Vt P^T
             const T* vt = Vs + buf * DV * VLD + l31 * VLD + hi * 8;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                if (kk < 2 * nb) {
+                if (FULL || kk < 2 * nb) {
 #pragma unroll
-                    for (int d = 0; d < NDB; ++d) {
-                        const T8 va = *reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16);
-                        st.o[d] = mfma32(va, pf[kk], st.o[d]);
-                    }
+                    for (int d = 0; d < NDB; ++d)
+                        st.o[d] = mfma32(*reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16), pf[kk], st.o[d]);
                 }
             }
+        };
+
+        const int nt = (L + KT - 1) / KT;
+        const int nfull = L / KT;
+        if (PREFETCH) {
+            if (nfull > 0) stage_load(0, std::true_type{});
+            else           stage_load(0, std::false_type{});
+            stage_write(0, 0);
+            __syncthreads();
+        }
+        int t = 0;
+        for (; t < nfull; ++t) {                        // tiles with all 64 keys valid: no masks, no edge logic
+            const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
+            if (PREFETCH) {
+                if (t + 1 < nfull)   stage_load(key0 + KT, std::true_type{});
+                else if (t + 1 < nt) stage_load(key0 + KT, std::false_type{});
+            } else {
+                stage_load(key0, std::true_type{});
+                stage_write(0, key0);
+                __syncthreads();
+            }
+            tile(buf, key0, std::true_type{});
             if (PREFETCH && t + 1 < nt) stage_write(buf ^ 1, key0 + KT);
+            __syncthreads();
+        }
+        if (t < nt) {                                   // ragged last tile
+            const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
+            if (!PREFETCH) {
+                stage_load(key0, std::false_type{});
+                stage_write(0, key0);
+                __syncthreads();
+            }
+            tile(buf, key0, std::false_type{});
             __syncthreads();
         }
     };
@@ -266,9 +328,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         st.m = -1e30f;
         st.l = 0.f;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st.o[d][r] = 0.f;
+        for (int d = 0; d < NDB; ++d) st.o[d] = zero16();
     };
 
     const T* k_own = Kg + (int64_t)kvf * a.k_fs;
@@ -299,9 +359,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     } else {
         if (a.fused) run(st, k_own, v_own, nullptr, nullptr, false, 0.f);
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) res[d][r] = 0.f;
+        for (int d = 0; d < NDB; ++d) res[d] = zero16();
         if (cf != 1.f) {                                    // begin side, weight (1 - c)
             OState<NDB> sb = st;
             run(sb, k_beg, v_beg, nullptr, nullptr, false, 0.f);
@@ -358,40 +416,37 @@ static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-static int attn_nw(const AidAttnArgs& a);
+// small images: one wave per workgroup so the grid still covers the 256 CUs
+static int attn_nw(const AidAttnArgs& a) { return ((int64_t)a.s * a.n_frames * a.heads >= 128 * 256) ? 4 : 1; }
 
 template <typename T, int D, int MODE>
-static hipError_t launch_nw(AttnKParams& p, hipStream_t stream, int* nw_out) {
-    // small images: one wave per workgroup so the grid still covers the 256 CUs
+static hipError_t launch_nw(AttnKParams& p, hipStream_t stream) {
     const int nw = attn_nw(p.a);
-    *nw_out = nw;
     p.nqb = (p.a.s + 32 * nw - 1) / (32 * nw);
     return nw == 4 ? launch_variant<T, D, MODE, 4>(p, stream) : launch_variant<T, D, MODE, 1>(p, stream);
 }
 
 template <typename T, int D>
-static hipError_t launch_mode(AttnKParams& p, hipStream_t stream, int* nw_out) {
+static hipError_t launch_mode(AttnKParams& p, hipStream_t stream) {
     switch (p.a.mode) {
-        case AID_MODE_PLAIN: return launch_nw<T, D, AID_MODE_PLAIN>(p, stream, nw_out);
-        case AID_MODE_INNER: return launch_nw<T, D, AID_MODE_INNER>(p, stream, nw_out);
-        default:             return launch_nw<T, D, AID_MODE_OUTER>(p, stream, nw_out);
+        case AID_MODE_PLAIN: return launch_nw<T, D, AID_MODE_PLAIN>(p, stream);
+        case AID_MODE_INNER: return launch_nw<T, D, AID_MODE_INNER>(p, stream);
+        default:             return launch_nw<T, D, AID_MODE_OUTER>(p, stream);
     }
 }
 
 template <typename T>
-static hipError_t launch_d(AttnKParams& p, hipStream_t stream, int* nw_out) {
+static hipError_t launch_d(AttnKParams& p, hipStream_t stream) {
     switch (p.a.d) {
-        case 40:  return launch_mode<T, 40>(p, stream, nw_out);
-        case 64:  return launch_mode<T, 64>(p, stream, nw_out);
-        case 80:  return launch_mode<T, 80>(p, stream, nw_out);
-        case 160: return launch_mode<T, 160>(p, stream, nw_out);
+        case 40:  return launch_mode<T, 40>(p, stream);
+        case 64:  return launch_mode<T, 64>(p, stream);
+        case 80:  return launch_mode<T, 80>(p, stream);
+        case 160: return launch_mode<T, 160>(p, stream);
         default:  return hipErrorInvalidValue;
     }
 }
 
 bool attn_head_dim_supported(int d) { return d == 40 || d == 64 || d == 80 || d == 160; }
-
-static int attn_nw(const AidAttnArgs& a) { return ((int64_t)a.s * a.n_frames * a.heads >= 128 * 512) ? 4 : 1; }
 
 const char* attn_variant_name(const AidAttnArgs& a) {
     static thread_local char name[64];
@@ -406,8 +461,7 @@ hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** va
     p.a = a;
     p.nqb = 0;
     p.c2 = a.softmax_scale * 1.4426950408889634f;
-    int nw = 0;
-    hipError_t e = (a.dtype == AID_DTYPE_F16) ? launch_d<f16>(p, stream, &nw) : launch_d<bf16>(p, stream, &nw);
+    hipError_t e = (a.dtype == AID_DTYPE_F16) ? launch_d<f16>(p, stream) : launch_d<bf16>(p, stream);
     if (variant) *variant = attn_variant_name(a);
     return e;
 }
