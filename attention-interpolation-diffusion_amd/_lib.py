@@ -22,7 +22,7 @@ GEMM_MAX_PROBLEMS = 4
 
 # every symbol include/aid_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "aid_gemm_nt", "aid_attn_fwd", "aid_processor_workspace_bytes", "aid_processor_fwd",
+    "aid_gemm_nt", "aid_attn_fwd", "aid_lerp_kv", "aid_processor_workspace_bytes", "aid_processor_fwd",
     "aid_abi_version", "aid_strerror", "aid_last_attn_variant", "aid_device_info",
     "aid_profile_begin", "aid_profile_end",
 )
@@ -42,6 +42,7 @@ class AidAttnArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
         ("coef", C.c_void_p), ("frame_scale", C.c_void_p), ("kv_map", C.c_void_p),
+        ("k2", C.c_void_p), ("vt2", C.c_void_p),
         ("n_frames", C.c_int32), ("n_kv", C.c_int32),
         ("s", C.c_int32), ("l", C.c_int32), ("heads", C.c_int32), ("d", C.c_int32),
         ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldvt", C.c_int32), ("ldo", C.c_int32),
@@ -103,6 +104,9 @@ def load() -> C.CDLL:
     lib.aid_gemm_nt.argtypes = [C.POINTER(AidGemmProblem), C.c_int, C.c_int, C.c_void_p]
     lib.aid_attn_fwd.restype = C.c_int
     lib.aid_attn_fwd.argtypes = [C.POINTER(AidAttnArgs), C.c_void_p]
+    lib.aid_lerp_kv.restype = C.c_int
+    lib.aid_lerp_kv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]
     lib.aid_processor_workspace_bytes.restype = C.c_size_t
     lib.aid_processor_workspace_bytes.argtypes = [C.POINTER(AidProcessorArgs)]
     lib.aid_processor_fwd.restype = C.c_int

@@ -62,7 +62,7 @@ int check_problem(const AidGemmProblem& q) {
 }
 
 struct Carve {
-    size_t q, k, vt, o, total;
+    size_t q, k, vt, o, k2, vt2, total;
     int lp;
 };
 
@@ -77,6 +77,11 @@ Carve carve(const AidProcessorArgs& a) {
     c.k = off;  off += align_up((size_t)nctx * l * a.c * es, 256);
     c.vt = off; off += align_up((size_t)nctx * a.c * c.lp * es, 256);
     c.o = off;  off += align_up((size_t)a.n_frames * a.s * a.c * es, 256);
+    c.k2 = c.vt2 = off;
+    if (a.mode == AID_MODE_INNER) {                       // interpolated K / V^T, one row per frame
+        c.k2 = off;  off += align_up((size_t)a.n_frames * l * a.c * es, 256);
+        c.vt2 = off; off += align_up((size_t)a.n_frames * a.c * c.lp * es, 256);
+    }
     c.total = off;
     return c;
 }
@@ -210,6 +215,7 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     if (a.mode != AID_MODE_PLAIN && (!a.coef || a.begin < 0 || a.begin >= a.n_kv || a.end < 0 || a.end >= a.n_kv))
         return AID_ERR_ARG;
     if (!a.kv_map && a.n_kv < a.n_frames) return AID_ERR_ARG;
+    if (a.mode == AID_MODE_INNER && (!a.k2 || !a.vt2 || !aligned16(a.k2) || !aligned16(a.vt2))) return AID_ERR_ARG;
     if (!aid::attn_head_dim_supported(a.d)) return AID_ERR_SHAPE;
     if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4 || a.ldvt < a.l) return AID_ERR_SHAPE;
     if (a.q_fs % 8 || a.k_fs % 8 || a.vt_fs % 8 || a.o_fs % 4) return AID_ERR_SHAPE;
@@ -227,6 +233,22 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
         e = aid::attn_launch(a, static_cast<hipStream_t>(stream), &g_variant);
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
+}
+
+int aid_lerp_kv(const void* k, const void* vt, void* k2, void* vt2, const float* coef, int32_t n_frames, int32_t begin,
+                int32_t end, int64_t k_fs, int64_t vt_fs, int32_t dtype, void* stream) {
+    if (!k || !vt || !k2 || !vt2 || !coef || n_frames < 1 || begin < 0 || end < 0) return AID_ERR_ARG;
+    if (dtype != AID_DTYPE_F16 && dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (k_fs % 8 || vt_fs % 8 || !aligned16(k) || !aligned16(vt) || !aligned16(k2) || !aligned16(vt2)) return AID_ERR_SHAPE;
+    hipError_t e;
+    {
+        const double bytes = 2.0 * 3.0 * n_frames * (double)(k_fs + vt_fs);
+        ProfScope ps(static_cast<hipStream_t>(stream), dtype == AID_DTYPE_F16 ? "aid_lerp_kv<f16>" : "aid_lerp_kv<bf16>",
+                     3.0 * n_frames * (double)(k_fs + vt_fs), bytes);
+        e = aid::lerp_kv_launch(k, vt, k2, vt2, coef, n_frames, begin, end, k_fs, vt_fs, dtype,
+                                static_cast<hipStream_t>(stream));
+    }
+    return e == hipSuccess ? AID_OK : fail_hip(e, "aid_lerp_kv");
 }
 
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args) {
@@ -269,10 +291,17 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     rc = aid_gemm_nt(pr, 3, a.dtype, stream);
     if (rc != AID_OK) return rc;
 
-    // 2. interpolated attention core
+    // 2. interpolated attention core (INNER: interpolated K / V^T of the interior frames first)
     AidAttnArgs at;
     memset(&at, 0, sizeof(at));
     at.q = q; at.k = k; at.vt = vt; at.out = o;
+    if (a.mode == AID_MODE_INNER) {
+        if (a.ctx_map) return AID_ERR_ARG;      // the lerped rows are per frame; shared-context maps are for PLAIN / OUTER
+        at.k2 = ws + cv.k2; at.vt2 = ws + cv.vt2;
+        rc = aid_lerp_kv(k, vt, ws + cv.k2, ws + cv.vt2, a.coef, a.n_frames, a.begin, a.end, (int64_t)l * a.c,
+                         (int64_t)a.c * cv.lp, a.dtype, stream);
+        if (rc != AID_OK) return rc;
+    }
     at.coef = a.coef; at.frame_scale = nullptr; at.kv_map = a.ctx_map;
     at.n_frames = a.n_frames; at.n_kv = nctx;
     at.s = a.s; at.l = l; at.heads = a.heads; at.d = d;

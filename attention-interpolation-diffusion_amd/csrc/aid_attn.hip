@@ -26,9 +26,12 @@
 // wave-uniform and taken before the tile's P is formed.
 // K / Vt tiles go global -> registers -> LDS (issued before the tile's compute, written after it,
 // two LDS buffers, one barrier per tile); the loads are branch-free (edge rows are clamped, never
-// predicated) and INNER lerps the two end-point tiles in registers on the way (the interpolated K/V
-// never exist in HBM).  LDS rows are padded by 16 B (odd 16-B stride): all fragment reads are
-// bank-conflict free.
+// predicated).  LDS rows are padded by 16 B (odd 16-B stride): all fragment reads are bank-conflict
+// free.
+// INNER reads the interpolated keys/values of an interior frame from k2 / vt2, which the tiny
+// element-wise kernel aid_lerp_kv_kernel below writes once per layer call: lerping the end-point
+// tiles inside this kernel was measured at +18 % kernel time because every one of the S/128
+// q-blocks of a (frame, head) repeated the same O(L*d) lerp.
 // OUTER shares the own-keys segment between its two softmaxes (3 segment passes, not 4): the online
 // state after the own segment is snapshotted and continued once with the begin and once with the
 // end frame; frames with coefficient exactly 0 / 1 skip the zero-weighted side.
@@ -144,14 +147,12 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     }
 
     // ---- one segment of keys: online-softmax update of `st` ----------------------------------
-    // k0/v0: frame base pointers (already offset to head h); k1/v1 + c: lerp partner (INNER).
-    auto run = [&](OState<NDB>& st, const T* k0, const T* v0, const T* k1, const T* v1, const bool lerp,
-                   const float c) __attribute__((always_inline)) {
-        T8 rk[NKC], rv[NVC], rk1[NKC], rv1[NVC];
+    // k0/v0: frame base pointers (already offset to head h)
+    auto run = [&](OState<NDB>& st, const T* k0, const T* v0) __attribute__((always_inline)) {
+        T8 rk[NKC], rv[NVC];
         // buffer descriptors of the segment's K / Vt (wave-uniform); per-lane byte offsets are 32-bit and the
         // tile advance goes into the scalar offset, so a full tile costs no address VALU at all
         const Rsrc sk0 = make_rsrc(k0), sv0 = make_rsrc(v0);
-        const Rsrc sk1 = make_rsrc(lerp ? k1 : k0), sv1 = make_rsrc(lerp ? v1 : v0);
         auto stage_load = [&](int key0, auto full_tag) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -163,7 +164,6 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     so = 0;
                 }
                 rk[i] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sk0, vo, so, 0));
-                if (lerp) rk1[i] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sk1, vo, so, 0));
             }
 #pragma unroll
             for (int i = 0; i < NVC; ++i) {
@@ -174,7 +174,6 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     so = 0;
                 }
                 rv[i] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sv0, vo, so, 0));
-                if (lerp) rv1[i] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sv1, vo, so, 0));
             }
         };
         auto stage_write = [&](int buf, int key0) __attribute__((always_inline)) {
@@ -185,13 +184,6 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 const int id = tid + i * NT;
                 if (NKC * NT != KCH && id >= KCH) continue;
                 T8 v = rk[i];
-                if (lerp) {
-                    const f32x8 x0 = up8<T>(rk[i]), x1 = up8<T>(rk1[i]);
-                    f32x8 y;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = fmaf(c, x1[e], (1.f - c) * x0[e]);
-                    v = cvt8<T>(y);
-                }
                 *reinterpret_cast<T8*>(ks + (id / DC) * KLD + (id % DC) * 8) = v;
             }
             const bool tail = key0 + KT > L;            // wave-uniform: the tile holds keys past the end
@@ -200,13 +192,6 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 const int id = tid + i * NT;
                 if (NVC * NT != VCH && id >= VCH) continue;
                 T8 v = rv[i];
-                if (lerp) {
-                    const f32x8 x0 = up8<T>(rv[i]), x1 = up8<T>(rv1[i]);
-                    f32x8 y;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = fmaf(c, x1[e], (1.f - c) * x0[e]);
-                    v = cvt8<T>(y);
-                }
                 if (tail) {                             // keys >= L get P = 0; their V must be finite
                     const int kc = min(key0 + (id % (KT / 8)) * 8, Lc8);
 #pragma unroll
@@ -343,32 +328,34 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     f32x16 res[NDB];
 
     if (MODE == AID_MODE_PLAIN) {
-        run(st, k_own, v_own, nullptr, nullptr, false, 0.f);
+        run(st, k_own, v_own);
         const float inv = 1.f / sum_halves(st.l);
 #pragma unroll
         for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
     } else if (MODE == AID_MODE_INNER) {
-        if (a.fused) run(st, k_own, v_own, nullptr, nullptr, false, 0.f);
-        // coefficient exactly 0 / 1: the lerp is the end-point frame itself
-        if (cf == 0.f)      run(st, k_beg, v_beg, nullptr, nullptr, false, 0.f);
-        else if (cf == 1.f) run(st, k_end, v_end, nullptr, nullptr, false, 0.f);
-        else                run(st, k_beg, v_beg, k_end, v_end, true, cf);
+        if (a.fused) run(st, k_own, v_own);
+        // coefficient exactly 0 / 1: the lerp is the end-point frame itself; interior frames read the
+        // interpolated keys / values that aid_lerp_kv wrote to k2 / vt2
+        if (cf == 0.f)      run(st, k_beg, v_beg);
+        else if (cf == 1.f) run(st, k_end, v_end);
+        else                run(st, reinterpret_cast<const T*>(a.k2) + h * D + (int64_t)fr * a.k_fs,
+                                reinterpret_cast<const T*>(a.vt2) + (int64_t)(h * D) * a.ldvt + (int64_t)fr * a.vt_fs);
         const float inv = 1.f / sum_halves(st.l);
 #pragma unroll
         for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
     } else {
-        if (a.fused) run(st, k_own, v_own, nullptr, nullptr, false, 0.f);
+        if (a.fused) run(st, k_own, v_own);
 #pragma unroll
         for (int d = 0; d < NDB; ++d) res[d] = zero16();
         if (cf != 1.f) {                                    // begin side, weight (1 - c)
             OState<NDB> sb = st;
-            run(sb, k_beg, v_beg, nullptr, nullptr, false, 0.f);
+            run(sb, k_beg, v_beg);
             const float w = (1.f - cf) / sum_halves(sb.l);
 #pragma unroll
             for (int d = 0; d < NDB; ++d) res[d] = sb.o[d] * w;
         }
         if (cf != 0.f) {                                    // end side, weight c
-            run(st, k_end, v_end, nullptr, nullptr, false, 0.f);
+            run(st, k_end, v_end);
             const float w = cf / sum_halves(st.l);
 #pragma unroll
             for (int d = 0; d < NDB; ++d) res[d] += st.o[d] * w;
@@ -444,6 +431,50 @@ static hipError_t launch_d(AttnKParams& p, hipStream_t stream) {
         case 160: return launch_mode<T, 160>(p, stream);
         default:  return hipErrorInvalidValue;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Interpolated keys / values of the interior frames (reference interpolation.py:772-775):
+//   k2[i] = (1 - c_i) k[begin] + c_i k[end]   (same for vt), frames with c_i in (0, 1) only — the
+// attention kernel reads the end-point frames themselves for c_i == 0 / 1.  Pure streaming
+// (HBM-bound): 16 B per lane, fp32 lerp, one rounding to the storage type.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void aid_lerp_kv_kernel(const T* __restrict__ k, const T* __restrict__ vt,
+                                                          T* __restrict__ k2, T* __restrict__ vt2,
+                                                          const float* __restrict__ coef, int n_frames, int begin,
+                                                          int end, int64_t k_fs, int64_t vt_fs) {
+    typedef typename Vec<T>::v8 T8;
+    const int fr = blockIdx.y;
+    const float c = coef[fr];
+    if (c == 0.f || c == 1.f) return;
+    const int64_t nk8 = k_fs / 8, nv8 = vt_fs / 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk8 + nv8; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool isk = i < nk8;
+        const int64_t j = isk ? i : i - nk8;
+        const T* src = isk ? k : vt;
+        const int64_t fs = isk ? k_fs : vt_fs;
+        const f32x8 x0 = up8<T>(*reinterpret_cast<const T8*>(src + begin * fs + j * 8));
+        const f32x8 x1 = up8<T>(*reinterpret_cast<const T8*>(src + end * fs + j * 8));
+        f32x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = fmaf(c, x1[e], (1.f - c) * x0[e]);
+        *reinterpret_cast<T8*>((isk ? k2 : vt2) + fr * fs + j * 8) = cvt8<T>(y);
+    }
+}
+
+hipError_t lerp_kv_launch(const void* k, const void* vt, void* k2, void* vt2, const float* coef, int n_frames, int begin,
+                          int end, int64_t k_fs, int64_t vt_fs, int dtype, hipStream_t stream) {
+    const int64_t n8 = (k_fs + vt_fs) / 8;
+    const int bx = (int)((n8 + 255) / 256 < 1024 ? (n8 + 255) / 256 : 1024);
+    dim3 grid(bx > 0 ? bx : 1, n_frames);
+    if (dtype == AID_DTYPE_F16)
+        hipLaunchKernelGGL(aid_lerp_kv_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)k, (const f16*)vt, (f16*)k2,
+                           (f16*)vt2, coef, n_frames, begin, end, k_fs, vt_fs);
+    else
+        hipLaunchKernelGGL(aid_lerp_kv_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)k, (const bf16*)vt,
+                           (bf16*)k2, (bf16*)vt2, coef, n_frames, begin, end, k_fs, vt_fs);
+    return hipGetLastError();
 }
 
 bool attn_head_dim_supported(int d) { return d == 40 || d == 64 || d == 80 || d == 160; }

@@ -28,6 +28,8 @@ hipError_t gemm_group_launch(const GemmGroup& g, int dtype, hipStream_t stream);
 // attention core; returns hipSuccess / error, writes the variant name for profiling
 hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** variant);
 bool       attn_head_dim_supported(int d);
+hipError_t lerp_kv_launch(const void* k, const void* vt, void* k2, void* vt2, const float* coef, int n_frames, int begin,
+                          int end, int64_t k_fs, int64_t vt_fs, int dtype, hipStream_t stream);
 const char* attn_variant_name(const AidAttnArgs& a);   // thread-local buffer
 
 }  // namespace aid

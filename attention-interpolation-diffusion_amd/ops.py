@@ -146,6 +146,15 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
     a = AidAttnArgs()
     a.q, a.k, a.vt, a.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
     a.coef, a.frame_scale, a.kv_map = _ptr(coef), _ptr(frame_scale), _ptr(kv_map)
+    if mode == "inner":
+        # interpolated K / V^T of the interior frames (one streaming launch), read by the attention kernel
+        if kv_map is not None or f != n:
+            raise ValueError("inner mode needs one key/value row per frame (no kv_map)")
+        k2, vt2 = torch.empty_like(k), torch.empty_like(vt)
+        _lib.check(lib.aid_lerp_kv(k.data_ptr(), vt.data_ptr(), k2.data_ptr(), vt2.data_ptr(), coef.data_ptr(), n,
+                                   begin % f, end % f, k.shape[1] * k.shape[2], vt.shape[1] * vt.shape[2], dt,
+                                   _stream()), "aid_lerp_kv")
+        a.k2, a.vt2 = k2.data_ptr(), vt2.data_ptr()
     a.n_frames, a.n_kv = n, f
     a.s, a.l, a.heads, a.d = s, l, heads, d
     a.ldq, a.ldk, a.ldvt, a.ldo = c, k.shape[2], vt.shape[2], out.shape[2]

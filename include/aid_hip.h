@@ -89,6 +89,8 @@ int aid_gemm_nt(const AidGemmProblem* problems /* host */, int n_problems, int d
  *   PLAIN : O_i = A(Q_i, K_i, V_i)
  *   INNER : Kc = (1-c_i) K[begin] + c_i K[end]  (same for V);
  *           O_i = fused ? A(Q_i, [K_i ; Kc], [V_i ; Vc]) : A(Q_i, Kc, Vc)
+ *           Kc / Vc^T of the interior frames (0 < c_i < 1) are read from k2 / vt2, laid out like k / vt
+ *           with one row per FRAME (frame strides k_fs / vt_fs); fill them with aid_lerp_kv() first.
  *   OUTER : O_i = (1-c_i) A(Q_i, [K_i;] K[begin], ..) + c_i A(Q_i, [K_i;] K[end], ..)
  * with A(Q,K,V) = softmax(Q K^T * softmax_scale) V per head, c_i = coef[i] (fp32, device).
  * Finally   out_i = (accumulate ? out_i : 0) + out_scale * (frame_scale ? frame_scale[i] : 1) * O_i.
@@ -102,6 +104,8 @@ typedef struct AidAttnArgs {
     const float*   coef;         /* device [n_frames]; may be NULL for PLAIN                 */
     const float*   frame_scale;  /* device [n_frames] or NULL                                */
     const int32_t* kv_map;       /* device [n_frames] or NULL (identity)                     */
+    const void*    k2;           /* INNER only: interpolated keys    [n_frames, l, heads*d]  */
+    const void*    vt2;          /* INNER only: interpolated values^T [n_frames, heads*d, ldvt] */
     int32_t n_frames, n_kv;
     int32_t s, l, heads, d;
     int32_t ldq, ldk, ldvt, ldo;
@@ -117,12 +121,22 @@ typedef struct AidAttnArgs {
 
 int aid_attn_fwd(const AidAttnArgs* args /* host */, void* stream);
 
+/* Interpolated keys / values for AID_MODE_INNER (reference interpolation.py:772-775):
+ *   k2[i] = (1 - coef[i]) * k[begin] + coef[i] * k[end]     (and the same for vt -> vt2)
+ * for every frame i with 0 < coef[i] < 1 (other frames are left untouched: the attention kernel reads
+ * the end-point frames themselves).  k_fs / vt_fs are the frame strides in elements (multiples of 8)
+ * of all four tensors.  One streaming launch. */
+int aid_lerp_kv(const void* k, const void* vt, void* k2, void* vt2, const float* coef /* device */,
+                int32_t n_frames, int32_t begin, int32_t end, int64_t k_fs, int64_t vt_fs, int32_t dtype,
+                void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * One whole processor call (what diffusers' Attention.forward hands to the AID processor):
  *   x   [n_frames, s, c]   hidden states          ctx [n_frames, l, cc] or NULL (self-attn: ctx = x)
  *   wq [c, c]  wk [c, cc]  wv [c, cc]  wo [c, c]  bo [c]      (torch Linear.weight layout [out, in])
  *   y   [n_frames, s, c]   = to_out( AID-attention( to_q(x), to_k(ctx), to_v(ctx) ) )
- * Launches: 1 grouped GEMM (q, k, V^T), 1 attention kernel, 1 GEMM (out-proj + bias).
+ * Launches: 1 grouped GEMM (q, k, V^T), [INNER: 1 streaming K/V lerp,] 1 attention kernel,
+ * 1 GEMM (out-proj + bias).
  * `workspace` must hold aid_processor_workspace_bytes() bytes (16-byte aligned); it is
  * scratch, owned by the caller, and may be reused by the next call on the same stream.
  * ------------------------------------------------------------------------------------- */
