@@ -177,14 +177,17 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BK, int NS>
-__global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_pipe_kernel(const GemmGroup g) {
+template <typename T, int BK, int NS, int NWV>
+__global__ __launch_bounds__(NWV * 64) void aid_gemm_nt_pipe_kernel(const GemmGroup g) {
     typedef typename Vec<T>::v8 T8;
     typedef typename Vec<T>::v4 T4;
     constexpr int RB = BK * 2;                          // bytes per tile row
     constexpr int CPR = RB / 16;                        // 16-B chunks per row (8 or 4)
     constexpr int RPI = 1024 / RB;                      // rows per wave DMA instruction (8 or 16)
-    constexpr int IPW = GBM / RPI / 4;                  // DMA instructions per wave per operand tile (4 or 2)
+    constexpr int NTHR = NWV * 64;
+    constexpr int WNW = NWV / 2;                        // waves along n (2 or 4); 2 waves along m
+    constexpr int NB = GBN / WNW / 32;                  // 32-wide n blocks per wave (2 or 1); 2 m blocks per wave
+    constexpr int IPW = GBM / RPI / NWV;                // DMA instructions per wave per operand tile
     constexpr int STAGE = (GBM + GBN) * RB;             // bytes per stage
     constexpr int DPT = 2 * IPW;                        // DMA instructions per wave per K tile
     static_assert(NS >= 2 && NS <= 4, "ring depth");
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_pipe_kernel(const GemmGr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave / WNW) * 64, wn = (wave % WNW) * (32 * NB);
     const int l31 = lane & 31, hi = lane >> 5;
 
     auto swz = [](int r) { return CPR == 8 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
@@ -229,19 +232,23 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_pipe_kernel(const GemmGr
     };
 
     // ---- fragment read offsets (bytes inside a stage) ----------------------------------------------
-    int aoff[2], boff[2], ax[2], bx[2];
+    int aoff[2], boff[NB], ax[2], bx[NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int ra = wm + i * 32 + l31, rb = wn + i * 32 + l31;
+        const int ra = wm + i * 32 + l31;
         aoff[i] = ra * RB;
-        boff[i] = GBM * RB + rb * RB;
         ax[i] = hi ^ swz(ra);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int rb = wn + i * 32 + l31;
+        boff[i] = GBM * RB + rb * RB;
         bx[i] = hi ^ swz(rb);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[NB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -262,24 +269,24 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_pipe_kernel(const GemmGr
         if (kt + NS - 1 < nk) dma(fill, (kt + NS - 1) * BK);
         const char* st = smem_raw + stage * STAGE;
         // fragment reads run one k-step ahead of the MFMAs that consume them
-        T8 fa[2][2], fb[2][2];
+        T8 fa[2][2], fb[2][NB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            fa[0][i] = *reinterpret_cast<const T8*>(st + aoff[i] + ((0 ^ ax[i]) << 4));
-            fb[0][i] = *reinterpret_cast<const T8*>(st + boff[i] + ((0 ^ bx[i]) << 4));
-        }
+        for (int i = 0; i < 2; ++i) fa[0][i] = *reinterpret_cast<const T8*>(st + aoff[i] + ((0 ^ ax[i]) << 4));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) fb[0][i] = *reinterpret_cast<const T8*>(st + boff[i] + ((0 ^ bx[i]) << 4));
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
             if (ks + 1 < BK / 16) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < 2; ++i)
                     fa[nxt][i] = *reinterpret_cast<const T8*>(st + aoff[i] + (((2 * ks + 2) ^ ax[i]) << 4));
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
                     fb[nxt][i] = *reinterpret_cast<const T8*>(st + boff[i] + (((2 * ks + 2) ^ bx[i]) << 4));
-                }
             }
 #pragma unroll
-            for (int in = 0; in < 2; ++in)
+            for (int in = 0; in < NB; ++in)
 #pragma unroll
                 for (int im = 0; im < 2; ++im) acc[in][im] = mfma32(fb[cur][in], fa[cur][im], acc[in][im]);
         }
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_pipe_kernel(const GemmGr
     const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
     const bool bias_vec = (reinterpret_cast<uintptr_t>(bias) & 7) == 0;
 #pragma unroll
-    for (int in = 0; in < 2; ++in)
+    for (int in = 0; in < NB; ++in)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int nl = wn + in * 32 + gq * 8 + hi * 4;
@@ -318,8 +325,8 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_pipe_kernel(const GemmGr
     __syncthreads();
     const bool vec_ok = (P.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #pragma unroll
-    for (int it = 0; it < (GBM * GBN / 8) / GTHREADS; ++it) {
-        const int id = tid + it * GTHREADS;
+    for (int it = 0; it < (GBM * GBN / 8) / NTHR; ++it) {
+        const int id = tid + it * NTHR;
         const int row = id >> 4, ch = (id & 15) * 8;
         const int m = m0 + row, n = n0 + ch;
         if (m >= P.m || n >= P.n) continue;
@@ -337,14 +344,14 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_pipe_kernel(const GemmGr
 
 template <typename K>
 static hipError_t launch_with_smem(K kernel, size_t smem, bool* attr_set, const GemmGroup& g, int total_tiles,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, int threads = GTHREADS) {
     if (!*attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         *attr_set = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(total_tiles), dim3(GTHREADS), smem, stream, g);
+    hipLaunchKernelGGL(kernel, dim3(total_tiles), dim3(threads), smem, stream, g);
     return hipGetLastError();
 }
 
@@ -355,21 +362,27 @@ static hipError_t launch_gemm(const GemmGroup& g, int total_tiles, hipStream_t s
         k64 = k64 && (g.p[i].k % 64 == 0);
         k32 = k32 && (g.p[i].k % 32 == 0);
     }
-    // development knob (tools/kbench.py): AID_GEMM_VARIANT = 0 edge, 1 BK64xNS2, 2 BK64xNS3, 3 BK64xNS4, 4 BK32xNS4
-    static const int variant = getenv("AID_GEMM_VARIANT") ? atoi(getenv("AID_GEMM_VARIANT")) : 1;
-    static bool s0 = false, s1 = false, s2 = false, s3 = false, s4 = false, s5 = false, s6 = false;
+    // development knob (tools/kbench.py): AID_GEMM_VARIANT = 0 edge, 1 BK64xNS2, 2 BK64xNS3, 3 BK64xNS4, 4 BK32xNS4,
+    // 5 BK32xNS3, 6 BK32xNS2 (4 waves); 7 BK64xNS2, 8 BK64xNS3 (8 waves, 64x32 wave tiles).  Default 7: best on the
+    // SD1.5 / SDXL projection shapes (measured, profiles/r01_gemm_variants.txt)
+    static const int variant = getenv("AID_GEMM_VARIANT") ? atoi(getenv("AID_GEMM_VARIANT")) : 7;
+    static bool s0 = false, s1 = false, s2 = false, s3 = false, s4 = false, s5 = false, s6 = false, s7 = false, s8 = false;
+    if (k64 && variant == 7)
+        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 64, 2, 8>, 2 * 32768, &s7, g, total_tiles, stream, 512);
+    if (k64 && variant == 8)
+        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 64, 3, 8>, 3 * 32768, &s8, g, total_tiles, stream, 512);
     if (k32 && variant == 5)
-        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 32, 3>, 3 * 16384, &s5, g, total_tiles, stream);
+        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 32, 3, 4>, 3 * 16384, &s5, g, total_tiles, stream);
     if (k32 && variant == 6)
-        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 32, 2>, GBM * G2_CLD * 2, &s6, g, total_tiles, stream);
+        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 32, 2, 4>, GBM * G2_CLD * 2, &s6, g, total_tiles, stream);
     if (k64 && variant == 1)
-        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 64, 2>, 2 * 32768, &s1, g, total_tiles, stream);
+        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 64, 2, 4>, 2 * 32768, &s1, g, total_tiles, stream);
     if (k64 && variant == 2)
-        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 64, 3>, 3 * 32768, &s2, g, total_tiles, stream);
+        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 64, 3, 4>, 3 * 32768, &s2, g, total_tiles, stream);
     if (k64 && variant == 3)
-        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 64, 4>, 4 * 32768, &s3, g, total_tiles, stream);
+        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 64, 4, 4>, 4 * 32768, &s3, g, total_tiles, stream);
     if (k32 && variant == 4)
-        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 32, 4>, 4 * 16384, &s4, g, total_tiles, stream);
+        return launch_with_smem(aid_gemm_nt_pipe_kernel<T, 32, 4, 4>, 4 * 16384, &s4, g, total_tiles, stream);
     return launch_with_smem(aid_gemm_nt_kernel<T>, (size_t)2 * (GBM + GBN) * GLD * sizeof(T), &s0, g, total_tiles, stream);
 }
 
