@@ -34,16 +34,16 @@ struct ProfScope {          // records an event pair around one launch when prof
     ProfScope(hipStream_t s, const char* name, double flops, double bytes) : stream(s), on(g_prof_on) {
         if (!on) return;
         ProfRec r;
-        hipEventCreate(&r.t0);
-        hipEventCreate(&r.t1);
+        (void)hipEventCreate(&r.t0);
+        (void)hipEventCreate(&r.t1);
         snprintf(r.name, sizeof(r.name), "%s", name);
         r.flops = flops;
         r.bytes = bytes;
-        hipEventRecord(r.t0, stream);
+        (void)hipEventRecord(r.t0, stream);
         g_prof.push_back(r);
     }
     ~ProfScope() {
-        if (on) hipEventRecord(g_prof.back().t1, stream);
+        if (on) (void)hipEventRecord(g_prof.back().t1, stream);
     }
 };
 
@@ -138,7 +138,7 @@ int aid_device_info(int* n_cu, int* clock_khz, char* arch) {
 }
 
 int aid_profile_begin(void) {
-    for (auto& r : g_prof) { hipEventDestroy(r.t0); hipEventDestroy(r.t1); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
     g_prof.clear();
     g_prof_on = true;
     return AID_OK;
@@ -160,8 +160,8 @@ int aid_profile_end(AidProfileEntry* entries, int max_entries) {
             entries[n].bytes = r.bytes;
             ++n;
         }
-        hipEventDestroy(r.t0);
-        hipEventDestroy(r.t1);
+        (void)hipEventDestroy(r.t0);
+        (void)hipEventDestroy(r.t1);
     }
     g_prof.clear();
     return rc == AID_OK ? n : rc;

@@ -58,6 +58,8 @@ def partition_frames(n_frames: int, world_size: int) -> List[Tuple[int, int]]:
 
 def frame_shard(n_frames: int, world_size: int, rank: int) -> FrameShard:
     start, stop = partition_frames(n_frames, world_size)[rank]
+    if stop == start:                         # more ranks than frames: this rank only replicates the end points
+        return FrameShard(n_frames, world_size, rank, (start, stop), (0, n_frames - 1), (0, 0))
     index: List[int] = []
     if start > 0:
         index.append(0)                       # replica of the begin frame

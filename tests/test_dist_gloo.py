@@ -1,0 +1,101 @@
+"""Frame sharding (attention-interpolation-diffusion_amd/dist.py) on CPU: pure partition logic plus a
+world_size-2 gloo run of the once-per-run collectives, with the oracle standing in for the kernels to
+show that the local batches [frame 0] + owned + [frame N-1] reproduce the unsharded result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import aid_amd
+from aid_amd import dist as adist
+from oracle import aid_oracle as O
+
+
+def test_partition_and_shard_layout():
+    assert adist.partition_frames(16, 8) == [(2 * i, 2 * i + 2) for i in range(8)]
+    assert adist.partition_frames(7, 2) == [(0, 4), (4, 7)]
+    assert adist.partition_frames(7, 1) == [(0, 7)]
+    with pytest.raises(ValueError):
+        adist.partition_frames(1, 1)
+    s = adist.frame_shard(16, 8, 3)
+    assert s.index == (0, 6, 7, 15) and s.owned_local == (1, 3) and s.n_local == 4 and s.n_owned == 2
+    s0, s7 = adist.frame_shard(16, 8, 0), adist.frame_shard(16, 8, 7)
+    assert s0.index == (0, 1, 15) and s0.owned_local == (0, 2)
+    assert s7.index == (0, 14, 15) and s7.owned_local == (1, 3)
+    # config 5: 8 frames on 8 GPUs -> interior ranks run exactly [start, own, end] (the reference's batch 3)
+    assert adist.frame_shard(8, 8, 4).index == (0, 4, 7)
+    # every frame is owned exactly once, every local batch starts with frame 0 and ends with frame N-1
+    for n, w in ((16, 8), (7, 2), (7, 4), (56, 8), (5, 8)):
+        owned = []
+        for r in range(w):
+            sh = adist.frame_shard(n, w, r)
+            assert sh.index[0] == 0 and sh.index[-1] == n - 1
+            owned += [sh.index[i] for i in range(*sh.owned_local)]
+        assert owned == list(range(n))
+    assert adist.expected_speedup(16, 8) == 4.0 and adist.expected_speedup(16, 1) == 1.0
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1002 + rank)                 # non-source ranks start with DIFFERENT data
+        heads, d, s, l = 2, 8, 6, 5
+        c = heads * d
+        cond = dict(x=torch.randn(n_frames, s, c), ctx=torch.randn(n_frames, l, c),
+                    coef=torch.rand(n_frames))
+        if rank == 0:
+            cond["coef"][0], cond["coef"][-1] = 0.0, 1.0
+        adist.broadcast_conditioning(cond, src=0)
+        shard = adist.frame_shard(n_frames, world, rank)
+        xq = adist.shard_rows(cond["x"], shard).numpy().astype(np.float64)
+        kv = adist.shard_rows(cond["ctx"], shard).numpy().astype(np.float64)
+        coef = adist.shard_rows(cond["coef"], shard).numpy()
+        outs = {}
+        for mode, fused in (("outer", True), ("inner", True), ("outer", False), ("plain", False)):
+            local = O.attn_core(xq, kv, kv, heads, d ** -0.5, mode, fused, coef)      # begin = row 0, end = last row
+            full = adist.gather_owned(torch.from_numpy(local), shard)
+            outs[f"{mode}{int(fused)}"] = full.numpy()
+        q.put((rank, {k: v.numpy() for k, v in cond.items()}, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [7, 4])
+def test_world_size_2_gloo_sharded_equals_unsharded(n_frames):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, cond0, out0), (_, cond1, out1) = res
+    for k in cond0:                                      # broadcast delivered rank 0's tensors
+        np.testing.assert_array_equal(cond0[k], cond1[k])
+    heads, d = 2, 8
+    x, kv, coef = (cond0[k].astype(np.float64) for k in ("x", "ctx", "coef"))
+    for key, full in out0.items():
+        mode, fused = key[:-1], bool(int(key[-1]))
+        ref = O.attn_core(x, kv, kv, heads, d ** -0.5, mode, fused, coef.astype(np.float32))
+        np.testing.assert_allclose(full, ref, atol=1e-12)   # identical maths, only the batch composition differs
+        np.testing.assert_array_equal(full, out1[key])     # all_gather gives every rank the same tensor
+
+
+def test_gather_owned_single_process():
+    sh = adist.frame_shard(5, 1, 0)
+    t = torch.arange(5.0).reshape(5, 1)
+    assert torch.equal(adist.gather_owned(t, sh), t)
