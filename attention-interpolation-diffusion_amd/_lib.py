@@ -50,6 +50,7 @@ class AidAttnArgs(C.Structure):
         ("mode", C.c_int32), ("fused", C.c_int32), ("begin", C.c_int32), ("end", C.c_int32),
         ("accumulate", C.c_int32), ("dtype", C.c_int32),
         ("softmax_scale", C.c_float), ("out_scale", C.c_float),
+        ("n_plain", C.c_int32), ("_pad", C.c_int32),
     ]
 
 
@@ -62,6 +63,7 @@ class AidProcessorArgs(C.Structure):
         ("cc", C.c_int32), ("heads", C.c_int32), ("mode", C.c_int32), ("fused", C.c_int32),
         ("begin", C.c_int32), ("end", C.c_int32), ("dtype", C.c_int32), ("n_ctx", C.c_int32),
         ("ctx_map", C.c_void_p),
+        ("n_plain", C.c_int32), ("_pad", C.c_int32),
     ]
 
 

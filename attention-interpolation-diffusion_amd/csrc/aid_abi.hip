@@ -224,7 +224,7 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     // pure outer 2, fused outer 3
     const int segs = a.mode == AID_MODE_PLAIN ? 1 : (a.mode == AID_MODE_INNER ? 1 : 2) + (a.fused ? 1 : 0);
     const double c = (double)a.heads * a.d;
-    const double flops = 4.0 * a.n_frames * a.s * ((double)segs * a.l) * c;
+    const double flops = 4.0 * a.s * (double)a.l * c * ((double)segs * (a.n_frames - a.n_plain) + a.n_plain);
     const double bytes = 2.0 * (2.0 * a.n_frames * a.s * c + 2.0 * a.n_kv * a.l * c);
     hipError_t e;
     {
@@ -235,20 +235,28 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
 }
 
-int aid_lerp_kv(const void* k, const void* vt, void* k2, void* vt2, const float* coef, int32_t n_frames, int32_t begin,
-                int32_t end, int64_t k_fs, int64_t vt_fs, int32_t dtype, void* stream) {
+static int lerp_kv_impl(const void* k, const void* vt, void* k2, void* vt2, const float* coef, int32_t n_frames,
+                        int32_t begin, int32_t end, int64_t k_fs, int64_t vt_fs, int32_t dtype, void* stream,
+                        int n_interior) {
     if (!k || !vt || !k2 || !vt2 || !coef || n_frames < 1 || begin < 0 || end < 0) return AID_ERR_ARG;
     if (dtype != AID_DTYPE_F16 && dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
     if (k_fs % 8 || vt_fs % 8 || !aligned16(k) || !aligned16(vt) || !aligned16(k2) || !aligned16(vt2)) return AID_ERR_SHAPE;
     hipError_t e;
     {
-        const double bytes = 2.0 * 3.0 * n_frames * (double)(k_fs + vt_fs);
+        // algorithmic traffic: the two end-point frames read once, one interpolated row written per interior frame
+        const double elems = (double)(k_fs + vt_fs);
         ProfScope ps(static_cast<hipStream_t>(stream), dtype == AID_DTYPE_F16 ? "aid_lerp_kv<f16>" : "aid_lerp_kv<bf16>",
-                     3.0 * n_frames * (double)(k_fs + vt_fs), bytes);
+                     3.0 * n_interior * elems, 2.0 * (2.0 + n_interior) * elems);
         e = aid::lerp_kv_launch(k, vt, k2, vt2, coef, n_frames, begin, end, k_fs, vt_fs, dtype,
                                 static_cast<hipStream_t>(stream));
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_lerp_kv");
+}
+
+int aid_lerp_kv(const void* k, const void* vt, void* k2, void* vt2, const float* coef, int32_t n_frames, int32_t begin,
+                int32_t end, int64_t k_fs, int64_t vt_fs, int32_t dtype, void* stream) {
+    return lerp_kv_impl(k, vt, k2, vt2, coef, n_frames, begin, end, k_fs, vt_fs, dtype, stream,
+                        n_frames > 2 ? n_frames - 2 : 0);
 }
 
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args) {
@@ -298,8 +306,9 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     if (a.mode == AID_MODE_INNER) {
         if (a.ctx_map) return AID_ERR_ARG;      // the lerped rows are per frame; shared-context maps are for PLAIN / OUTER
         at.k2 = ws + cv.k2; at.vt2 = ws + cv.vt2;
-        rc = aid_lerp_kv(k, vt, ws + cv.k2, ws + cv.vt2, a.coef, a.n_frames, a.begin, a.end, (int64_t)l * a.c,
-                         (int64_t)a.c * cv.lp, a.dtype, stream);
+        const int interior = a.n_frames - a.n_plain - 2;
+        rc = lerp_kv_impl(k, vt, ws + cv.k2, ws + cv.vt2, a.coef, a.n_frames, a.begin, a.end, (int64_t)l * a.c,
+                          (int64_t)a.c * cv.lp, a.dtype, stream, interior > 0 ? interior : 0);
         if (rc != AID_OK) return rc;
     }
     at.coef = a.coef; at.frame_scale = nullptr; at.kv_map = a.ctx_map;
@@ -311,6 +320,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     at.accumulate = 0; at.dtype = a.dtype;
     at.softmax_scale = 1.0f / sqrtf((float)d);
     at.out_scale = 1.0f;
+    at.n_plain = a.n_plain;
     rc = aid_attn_fwd(&at, stream);
     if (rc != AID_OK) return rc;
 

@@ -149,12 +149,13 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     // ---- one segment of keys: online-softmax update of `st` ----------------------------------
     // k0/v0: frame base pointers (already offset to head h)
     auto run = [&](OState<NDB>& st, const T* k0, const T* v0) __attribute__((always_inline)) {
-        T8 rk[NKC], rv[NVC];
+        T8 rk[PREFETCH ? NKC : 1], rv[PREFETCH ? NVC : 1];
         // buffer descriptors of the segment's K / Vt (wave-uniform); per-lane byte offsets are 32-bit and the
         // tile advance goes into the scalar offset, so a full tile costs no address VALU at all
         const Rsrc sk0 = make_rsrc(k0), sv0 = make_rsrc(v0);
         auto stage_load = [&](int key0, auto full_tag) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
+            if (!PREFETCH) return;
 #pragma unroll
             for (int i = 0; i < NKC; ++i) {
                 int vo = kvo[i], so = key0 * a.ldk * 2;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             }
         };
         auto stage_write = [&](int buf, int key0) __attribute__((always_inline)) {
+            if (!PREFETCH) return;
             T* ks = Ks + buf * KT * KLD;
             T* vs = Vs + buf * DV * VLD;
 #pragma unroll
@@ -199,6 +201,50 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                         if (kc + e >= L) v[e] = (T)0.0f;
                 }
                 *reinterpret_cast<T8*>(vs + (id / (KT / 8)) * VLD + (id % (KT / 8)) * 8) = v;
+            }
+        };
+
+        // Non-prefetch variants (one wave per workgroup, or d = 160): a whole tile would be 40 x 16 B of staging
+        // registers per lane, so it is staged synchronously in groups of 4 chunks (rolled loop, bounded registers).
+        auto stage_sync = [&](int key0) __attribute__((always_inline)) {
+            T* ks = Ks;
+            T* vs = Vs;
+            constexpr int G = 4;
+#pragma nounroll
+            for (int i0 = 0; i0 < NKC; i0 += G) {
+                T8 r[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int id = min(tid + (i0 + j) * NT, KCH - 1);
+                    const int vo = min(key0 + id / DC, L - 1) * (a.ldk * 2) + (id % DC) * 16;
+                    r[j] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sk0, vo, 0, 0));
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int id = tid + (i0 + j) * NT;
+                    if (id < KCH) *reinterpret_cast<T8*>(ks + (id / DC) * KLD + (id % DC) * 8) = r[j];
+                }
+            }
+#pragma nounroll
+            for (int i0 = 0; i0 < NVC; i0 += G) {
+                T8 r[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int id = min(tid + (i0 + j) * NT, VCH - 1);
+                    const int kc = min(key0 + (id % (KT / 8)) * 8, Lc8);
+                    r[j] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sv0, (id / (KT / 8)) * (a.ldvt * 2) + kc * 2, 0, 0));
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int id = tid + (i0 + j) * NT;
+                    if (id >= VCH) continue;
+                    const int kc = min(key0 + (id % (KT / 8)) * 8, Lc8);
+                    T8 v = r[j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (kc + e >= L) v[e] = (T)0.0f;         // keys >= L get P = 0; their V must be finite
+                    *reinterpret_cast<T8*>(vs + (id / (KT / 8)) * VLD + (id % (KT / 8)) * 8) = v;
+                }
             }
         };
 
@@ -289,8 +335,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 if (t + 1 < nfull)   stage_load(key0 + KT, std::true_type{});
                 else if (t + 1 < nt) stage_load(key0 + KT, std::false_type{});
             } else {
-                stage_load(key0, std::true_type{});
-                stage_write(0, key0);
+                stage_sync(key0);
                 __syncthreads();
             }
             tile(buf, key0, std::true_type{});
@@ -300,8 +345,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         if (t < nt) {                                   // ragged last tile
             const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
             if (!PREFETCH) {
-                stage_load(key0, std::false_type{});
-                stage_write(0, key0);
+                stage_sync(key0);
                 __syncthreads();
             }
             tile(buf, key0, std::false_type{});
@@ -328,6 +372,13 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     f32x16 res[NDB];
 
     if (MODE == AID_MODE_PLAIN) {
+        run(st, k_own, v_own);
+        const float inv = 1.f / sum_halves(st.l);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
+    } else if (cf < 0.f) {
+        // negative coefficient = this frame is PLAIN inside an INNER / OUTER launch (the unconditional half of a
+        // classifier-free-guidance batch rides in the same call)
         run(st, k_own, v_own);
         const float inv = 1.f / sum_halves(st.l);
 #pragma unroll
@@ -447,7 +498,7 @@ __global__ __launch_bounds__(256) void aid_lerp_kv_kernel(const T* __restrict__ 
     typedef typename Vec<T>::v8 T8;
     const int fr = blockIdx.y;
     const float c = coef[fr];
-    if (c == 0.f || c == 1.f) return;
+    if (c <= 0.f || c >= 1.f) return;      // end points and PLAIN-marked frames need no interpolated rows
     const int64_t nk8 = k_fs / 8, nv8 = vt_fs / 8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk8 + nv8; i += (int64_t)gridDim.x * blockDim.x) {
         const bool isk = i < nk8;

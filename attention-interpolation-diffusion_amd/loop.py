@@ -51,12 +51,14 @@ def install_sequence_processors(unet, size: int, early: str = "fused_outer", alp
     unet.set_attn_processor(procs)
 
 
-def set_aid_active(unet, active: bool) -> None:
+def set_aid_active(unet, active: bool, plain_tail: int = 0) -> None:
     """N-frame analogue of activate_aid / deactivate_aid that keeps the coefficient schedule
-    (the reference's activate(t) resets coef to [0, t, 1] for its batch-3 loop)."""
+    (the reference's activate(t) resets coef to [0, t, 1] for its batch-3 loop).  ``plain_tail`` frames
+    appended after the interpolated ones run plain attention in the same call (batched CFG)."""
     for proc in unet.attn_processors.values():
         if isinstance(proc, InterpolatedAttnProcessor):
             proc.activated = bool(active)
+            proc.plain_tail = int(plain_tail)
 
 
 class AidDenoiseLoop:
@@ -67,8 +69,19 @@ class AidDenoiseLoop:
     """
 
     def __init__(self, unet, sample, cond, uncond, num_inference_steps: int = 50, warmup_ratio: float = 0.5,
-                 guidance_scale: float = 7.5, use_graphs: bool = True, combine: Optional[Callable] = None):
+                 guidance_scale: float = 7.5, use_graphs: bool = True, combine: Optional[Callable] = None,
+                 batched_cfg: bool = False):
+        """``batched_cfg``: run the conditional and the unconditional pass of a step as ONE UNet call over the
+        batch [cond frames ; uncond frames] (how stock diffusers pipelines do classifier-free guidance).  The
+        AID processors treat the second half as plain riders (negative coefficients), so the result equals the
+        reference's two separate calls while every GEMM sees twice the rows and the launch count halves."""
         self.unet, self.sample, self.cond, self.uncond = unet, sample, cond, uncond
+        self.batched_cfg = batched_cfg
+        if batched_cfg:
+            dup = (lambda t: torch.cat([t, t], dim=0))
+            self.sample2 = {k: dup(v) for k, v in sample.items()} if isinstance(sample, dict) else dup(sample)
+            self.ctx2 = torch.cat([cond, uncond], dim=0)
+            self.n_frames = cond.shape[0]
         self.num_inference_steps = num_inference_steps
         self.warmup_steps = int(num_inference_steps * warmup_ratio)        # pipeline_interpolated_sd.py:1831
         self.guidance_scale = guidance_scale
@@ -84,8 +97,14 @@ class AidDenoiseLoop:
 
     # -- the three distinct passes ---------------------------------------------------------------
     def _pass(self, which: str):
+        if which == "both_aid":
+            set_aid_active(self.unet, True, plain_tail=self.n_frames)
+            return self.unet(self.sample2, self.ctx2)
+        if which == "both_plain":
+            set_aid_active(self.unet, False)
+            return self.unet(self.sample2, self.ctx2)
         if which == "cond_aid":
-            set_aid_active(self.unet, True)
+            set_aid_active(self.unet, True, plain_tail=0)
             return self.unet(self.sample, self.cond)
         set_aid_active(self.unet, False)
         return self.unet(self.sample, self.cond if which == "cond_plain" else self.uncond)
@@ -113,6 +132,12 @@ class AidDenoiseLoop:
         return i < self.warmup_steps
 
     def step(self, i: int):
+        if self.batched_cfg:
+            both = self._run("both_aid" if self.aid_on(i) else "both_plain")
+            n = self.n_frames
+            if isinstance(both, dict):
+                return self.combine({k: v[:n] for k, v in both.items()}, {k: v[n:] for k, v in both.items()})
+            return self.combine(both[:n], both[n:])
         text = self._run("cond_aid" if self.aid_on(i) else "cond_plain")
         unc = self._run("uncond")
         return self.combine(text, unc)

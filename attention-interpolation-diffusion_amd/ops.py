@@ -122,7 +122,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
              begin: int = 0, end: int = -1, out: Optional[torch.Tensor] = None,
              accumulate: bool = False, out_scale: float = 1.0,
              frame_scale: Optional[torch.Tensor] = None, kv_map: Optional[torch.Tensor] = None,
-             softmax_scale: Optional[float] = None) -> torch.Tensor:
+             softmax_scale: Optional[float] = None, n_plain: int = 0) -> torch.Tensor:
     """Interpolated attention core (see AidAttnArgs in include/aid_hip.h).
     q [N, S, C], k [F, L, C], vt [F, C, Lp] contiguous; coef / frame_scale fp32 device [N]."""
     lib = _lib.load()
@@ -164,6 +164,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
     a.accumulate, a.dtype = int(bool(accumulate)), dt
     a.softmax_scale = float(d ** -0.5 if softmax_scale is None else softmax_scale)
     a.out_scale = float(out_scale)
+    a.n_plain = int(n_plain)
     _lib.check(lib.aid_attn_fwd(C.byref(a), _stream()), "aid_attn_fwd")
     return out
 
@@ -176,7 +177,7 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
                   wv: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], heads: int, *,
                   mode: str = "plain", fused: bool = False, coef: Optional[torch.Tensor] = None,
                   begin: int = 0, end: int = -1, ctx_map: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, n_plain: int = 0) -> torch.Tensor:
     """One whole processor call: y = to_out(AID-attention(to_q(x), to_k(ctx), to_v(ctx)))
     in three launches (grouped q/k/V^T GEMM, attention core, out-proj GEMM)."""
     lib = _lib.load()
@@ -204,6 +205,7 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
     a.mode, a.fused = MODES[mode], int(bool(fused))
     a.begin, a.end = begin % nkv, end % nkv
     a.dtype = dt
+    a.n_plain = int(n_plain)
     nbytes = lib.aid_processor_workspace_bytes(C.byref(a))
     if nbytes == 0:
         # let the library say why

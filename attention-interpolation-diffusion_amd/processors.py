@@ -44,6 +44,9 @@ class InterpolatedAttnProcessor(nn.Module):
         self.coef = ts
         self.is_fused = is_fused
         self.activated = True
+        # build-specific: number of extra frames appended AFTER the `size` interpolated frames that run plain
+        # attention in the same call (the unconditional half of a batched classifier-free-guidance step)
+        self.plain_tail = 0
         self._coef_cache: Dict[Tuple, torch.Tensor] = {}
 
     def deactivate(self):
@@ -65,15 +68,18 @@ class InterpolatedAttnProcessor(nn.Module):
         """``coef.to(key.device, key.dtype)`` (interpolation.py:663: coefficients are rounded to
         the compute dtype) kept resident on the device as fp32 for the kernel."""
         coef = self.coef
-        if coef.numel() != batch:
+        if coef.numel() + self.plain_tail != batch:
             # the reference fails at the broadcast of the lerp (interpolation.py:664 / 774)
-            raise RuntimeError(f"The size of tensor a ({coef.numel()}) must match the size of tensor b "
-                               f"({batch}) at non-singleton dimension 0")
-        key = (id(coef), coef._version, device, dtype)
+            raise RuntimeError(f"The size of tensor a ({coef.numel() + self.plain_tail}) must match the size of "
+                               f"tensor b ({batch}) at non-singleton dimension 0")
+        key = (id(coef), coef._version, device, dtype, self.plain_tail)
         hit = self._coef_cache.get(key)
         if hit is None:
             self._coef_cache.clear()
-            hit = coef.detach().to(torch.float32).to(dtype).to(torch.float32).to(device).contiguous()
+            hit = coef.detach().to(torch.float32).to(dtype).to(torch.float32)
+            if self.plain_tail:                       # negative coefficient = PLAIN rider frame (aid_hip.h)
+                hit = torch.cat([hit, -torch.ones(self.plain_tail)])
+            hit = hit.to(device).contiguous()
             self._coef_cache[key] = hit
         return hit
 
@@ -128,8 +134,11 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
         coef = proc._coef_device(x.device, x.dtype, x.shape[0])
     if ctx is not None:
         ctx = ctx.contiguous()
+    n_aid = proc.coef.numel()
     y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode,
-                          fused=proc.is_fused if mode != "plain" else False, coef=coef)
+                          fused=proc.is_fused if mode != "plain" else False, coef=coef,
+                          begin=0, end=(n_aid - 1) if mode != "plain" else -1,
+                          n_plain=proc.plain_tail if mode != "plain" else 0)
     return _epilogue(attn, y, residual, shape4)
 
 

@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--frames-per-gpu", type=int, default=7)
     ap.add_argument("--warmup-ratio", type=float, default=0.5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--separate-passes", action="store_true",
+                    help="run the cond and the uncond pass as two UNet calls like the reference loop "
+                         "(default: one call over [cond ; uncond], same work, same results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -173,7 +176,7 @@ def main():
     install_sequence_processors(unet, shard.n_local, early=early, num_inference_steps=steps, coef=local_coef)
 
     loop = AidDenoiseLoop(unet, xs, cond, uncond, num_inference_steps=steps, warmup_ratio=args.warmup_ratio,
-                          use_graphs=not args.no_graph)
+                          use_graphs=not args.no_graph, batched_cfg=not args.separate_passes)
     gather_key = unet.level_shapes()[-1]
 
     def run_steps(idx):
@@ -216,7 +219,9 @@ def main():
                          else "BASELINE configs[2]: SDXL-base 1024x1024 attention stack (140 attention calls / UNet pass)"),
             "frames": n_total, "frames_per_gpu": args.frames_per_gpu, "local_batch": shard.n_local,
             "early": early, "late": "plain", "warmup_ratio": args.warmup_ratio,
-            "aid_steps": loop.warmup_steps, "passes_per_step": "cond + uncond (CFG)",
+            "aid_steps": loop.warmup_steps,
+            "passes_per_step": ("cond + uncond (CFG), two UNet calls" if args.separate_passes
+                                else "cond + uncond (CFG) batched in one UNet call [cond ; uncond]"),
             "coef": f"BetaPPF(alpha=beta={steps})", "hipgraph": not args.no_graph,
             "parallelism": f"frame-shard x{world} (replicated end points, no per-layer collective)",
         },

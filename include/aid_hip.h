@@ -93,6 +93,9 @@ int aid_gemm_nt(const AidGemmProblem* problems /* host */, int n_problems, int d
  *           with one row per FRAME (frame strides k_fs / vt_fs); fill them with aid_lerp_kv() first.
  *   OUTER : O_i = (1-c_i) A(Q_i, [K_i;] K[begin], ..) + c_i A(Q_i, [K_i;] K[end], ..)
  * with A(Q,K,V) = softmax(Q K^T * softmax_scale) V per head, c_i = coef[i] (fp32, device).
+ * A NEGATIVE coefficient marks frame i as PLAIN inside an INNER / OUTER launch: the unconditional half of a
+ * classifier-free-guidance batch [cond frames ; uncond frames] then rides in the same call (begin / end must
+ * index the cond half).  n_plain = number of such frames (host-side accounting only, may be 0).
  * Finally   out_i = (accumulate ? out_i : 0) + out_scale * (frame_scale ? frame_scale[i] : 1) * O_i.
  * Supported head dims d: 40, 64, 80, 160 (SD1.5 / SDXL).  No sequence-length restriction.
  * ------------------------------------------------------------------------------------- */
@@ -117,6 +120,8 @@ typedef struct AidAttnArgs {
     int32_t dtype;               /* AID_DTYPE_*                                              */
     float   softmax_scale;       /* d^-0.5 for diffusers Attention                           */
     float   out_scale;
+    int32_t n_plain;             /* frames with a negative coefficient (profiling accounting) */
+    int32_t _pad;
 } AidAttnArgs;
 
 int aid_attn_fwd(const AidAttnArgs* args /* host */, void* stream);
@@ -159,6 +164,8 @@ typedef struct AidProcessorArgs {
     int32_t dtype;
     int32_t n_ctx;               /* number of ctx frames (n_frames, or fewer with ctx_map)   */
     const int32_t* ctx_map;      /* device [n_frames] frame -> ctx row, or NULL (identity)   */
+    int32_t n_plain;             /* frames whose coef is negative (PLAIN riders), accounting  */
+    int32_t _pad;
 } AidProcessorArgs;
 
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args /* host */);

@@ -314,3 +314,32 @@ def test_full_size_layer_properties(model, dtype):
     o2 = ops.attn_fwd(q, k, v2.transpose(1, 2).contiguous(), h, l=s, mode="outer", fused=True, coef=coef)
     o12 = ops.attn_fwd(q, k, (v + v2).transpose(1, 2).contiguous(), h, l=s, mode="outer", fused=True, coef=coef)
     assert rel_l2(to_np64(o12), to_np64(o1) + to_np64(o2)) < 2 * TOL[dtype]                      # (c)
+
+
+# ------------------------------------------------------------------------------------------------
+# batched classifier-free guidance: [cond frames ; uncond frames] in ONE call (plain rider frames)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("kind", ["outer", "inner"])
+@pytest.mark.parametrize("cross", [False, True])
+def test_batched_cfg_equals_two_separate_calls(dtype, kind, cross):
+    n, s, heads, d, l, cc = 5, 150, 2, 64, 77, 96
+    c = heads * d
+    g = torch.Generator().manual_seed(21)
+    attn = aid_amd.AttnShim(c, heads, cc if cross else None, dtype=dtype, device=DEV)
+    xc = torch.randn(n, s, c, generator=g).to(dtype).to(DEV)
+    xu = torch.randn(n, s, c, generator=g).to(dtype).to(DEV)
+    cc_ = torch.randn(n, l, cc, generator=g).to(dtype).to(DEV) if cross else None
+    cu_ = torch.randn(n, l, cc, generator=g).to(dtype).to(DEV) if cross else None
+    cls = aid_amd.OuterInterpolatedAttnProcessor if kind == "outer" else aid_amd.InnerInterpolatedAttnProcessor
+    proc = cls(size=n, is_fused=True, alpha=3, beta=3)
+    y_cond = proc(attn, xc, encoder_hidden_states=cc_)                      # reference structure: AID pass ...
+    y_unc = aid_amd.HipAttnProcessor()(attn, xu, encoder_hidden_states=cu_)  # ... then the plain pass
+    proc.plain_tail = n
+    both = proc(attn, torch.cat([xc, xu]), encoder_hidden_states=None if not cross else torch.cat([cc_, cu_]))
+    assert both.shape[0] == 2 * n
+    assert torch.equal(both[:n], y_cond)          # same kernels, same tiles -> bitwise
+    assert torch.equal(both[n:], y_unc)
+    proc.plain_tail = 0
+    with pytest.raises(RuntimeError, match="must match the size"):
+        proc(attn, torch.cat([xc, xu]))
