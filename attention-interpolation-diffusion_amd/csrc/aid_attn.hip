@@ -35,6 +35,8 @@
 // OUTER shares the own-keys segment between its two softmaxes (3 segment passes, not 4): the online
 // state after the own segment is snapshotted and continued once with the begin and once with the
 // end frame; frames with coefficient exactly 0 / 1 skip the zero-weighted side.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "aid_common.hpp"
@@ -454,14 +456,14 @@ static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// small images: one wave per workgroup so the grid still covers the 256 CUs
-static int attn_nw(const AidAttnArgs& a) { return ((int64_t)a.s * a.n_frames * a.heads >= 128 * 256) ? 4 : 1; }
+// Four waves (128 query rows) per workgroup for every shape: one-wave workgroups were measured slower
+// even at S = 64 (profiles/r01_attn_small_shapes.txt) — the K/V staging cost per query row quadruples.
+static int attn_nw(const AidAttnArgs&) { return 4; }
 
 template <typename T, int D, int MODE>
 static hipError_t launch_nw(AttnKParams& p, hipStream_t stream) {
-    const int nw = attn_nw(p.a);
-    p.nqb = (p.a.s + 32 * nw - 1) / (32 * nw);
-    return nw == 4 ? launch_variant<T, D, MODE, 4>(p, stream) : launch_variant<T, D, MODE, 1>(p, stream);
+    p.nqb = (p.a.s + 127) / 128;
+    return launch_variant<T, D, MODE, 4>(p, stream);
 }
 
 template <typename T, int D>
