@@ -179,7 +179,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 rv[i] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sv0, vo, so, 0));
             }
         };
-        auto stage_write = [&](int buf, int key0) __attribute__((always_inline)) {
+        auto stage_write = [&](int buf, int key0, auto full_tag) __attribute__((always_inline)) {
+            constexpr bool WFULL = decltype(full_tag)::value;     // tile written has all 64 keys valid
             if (!PREFETCH) return;
             T* ks = Ks + buf * KT * KLD;
             T* vs = Vs + buf * DV * VLD;
@@ -190,13 +191,13 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 T8 v = rk[i];
                 *reinterpret_cast<T8*>(ks + (id / DC) * KLD + (id % DC) * 8) = v;
             }
-            const bool tail = key0 + KT > L;            // wave-uniform: the tile holds keys past the end
 #pragma unroll
             for (int i = 0; i < NVC; ++i) {
                 const int id = tid + i * NT;
                 if (NVC * NT != VCH && id >= VCH) continue;
                 T8 v = rv[i];
-                if (tail) {                             // keys >= L get P = 0; their V must be finite
+                if (!WFULL) {                           // keys >= L get P = 0; their V must be finite
+                    asm volatile("; ragged Vt tile" ::: "memory");   // keeps hipcc from if-converting this into the hot path
                     const int kc = min(key0 + (id % (KT / 8)) * 8, Lc8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -295,8 +296,10 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st.o[d][r] *= alpha;
             }
+            // scalar fp32 VALU on purpose: the packed forms (v_pk_fma_f32 / v_pk_add_f32) were measured 8 % slower
+            // here (profiles/r01_attn_notes.txt) — they issue at half rate beside the MFMAs
             const float mc = st.m * c2;
-            float ps0 = 0.f, ps1 = 0.f;
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};                     // independent row-sum chains
             T8 pf[4];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -304,12 +307,13 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 for (int u = 0; u < 2; ++u) {
                     f32x8 pv;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(fmaf(sc[b][8 * u + e], c2, -mc));
-                    ps0 += (pv[0] + pv[1]) + (pv[2] + pv[3]);
-                    ps1 += (pv[4] + pv[5]) + (pv[6] + pv[7]);
+                    for (int e = 0; e < 8; ++e) {
+                        pv[e] = __builtin_amdgcn_exp2f(fmaf(sc[b][8 * u + e], c2, -mc));
+                        ps[e & 3] += pv[e];
+                    }
                     pf[2 * b + u] = cvt8<T>(pv);
                 }
-            st.l += ps0 + ps1;
+            st.l += (ps[0] + ps[1]) + (ps[2] + ps[3]);
             // O^T += Vt P^T
             const T* vt = Vs + buf * DV * VLD + l31 * VLD + hi * 8;
 #pragma unroll
@@ -327,7 +331,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         if (PREFETCH) {
             if (nfull > 0) stage_load(0, std::true_type{});
             else           stage_load(0, std::false_type{});
-            stage_write(0, 0);
+            if (nfull > 0) stage_write(0, 0, std::true_type{});
+            else           stage_write(0, 0, std::false_type{});
             __syncthreads();
         }
         int t = 0;
@@ -341,7 +346,10 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 __syncthreads();
             }
             tile(buf, key0, std::true_type{});
-            if (PREFETCH && t + 1 < nt) stage_write(buf ^ 1, key0 + KT);
+            if (PREFETCH) {
+                if (t + 1 < nfull)   stage_write(buf ^ 1, key0 + KT, std::true_type{});
+                else if (t + 1 < nt) stage_write(buf ^ 1, key0 + KT, std::false_type{});
+            }
             __syncthreads();
         }
         if (t < nt) {                                   // ragged last tile
