@@ -173,7 +173,6 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
     aid::GemmGroup g;
     memset(&g, 0, sizeof(g));
     g.n_problems = n_problems;
-    int tiles = 0;
     for (int i = 0; i < n_problems; ++i) {
         const AidGemmProblem& q = problems[i];
         int rc = check_problem(q);
@@ -182,11 +181,9 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
         d.a = q.a; d.b = q.b; d.c = q.c; d.bias = q.bias;
         d.m = q.m; d.n = q.n; d.k = q.k;
         d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc;
+        d.batch = q.batch;
         d.stride_a = q.stride_a; d.stride_b = q.stride_b; d.stride_c = q.stride_c;
-        g.tile_start[i] = tiles;
-        tiles += aid::gemm_tiles(q.m, q.n, q.batch);
     }
-    for (int i = n_problems; i <= AID_GEMM_MAX_PROBLEMS; ++i) g.tile_start[i] = tiles;
     double flops = 0, bytes = 0;
     if (g_prof_on) {
         for (int i = 0; i < n_problems; ++i) {

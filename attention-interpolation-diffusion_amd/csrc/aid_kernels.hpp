@@ -13,17 +13,18 @@ struct GemmDesc {
     const void* bias;
     int32_t m, n, k;
     int32_t lda, ldb, ldc;
+    int32_t batch, _pad;
     int64_t stride_a, stride_b, stride_c;
 };
 
 struct GemmGroup {                        // passed by value as the kernel argument
     GemmDesc p[AID_GEMM_MAX_PROBLEMS];
-    int32_t  tile_start[AID_GEMM_MAX_PROBLEMS + 1];   // prefix sums of block counts
+    int32_t  tile_start[AID_GEMM_MAX_PROBLEMS + 1];   // prefix sums of block counts (filled by the launcher)
     int32_t  n_problems;
 };
 
-int        gemm_tiles(int m, int n, int batch);
-hipError_t gemm_group_launch(const GemmGroup& g, int dtype, hipStream_t stream);
+// picks the tile shape, fills g.tile_start and launches
+hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream);
 
 // attention core; returns hipSuccess / error, writes the variant name for profiling
 hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** variant);

@@ -73,6 +73,10 @@ def frame_shard(n_frames: int, world_size: int, rank: int) -> FrameShard:
     return FrameShard(n_frames, world_size, rank, (start, stop), tuple(index), (own_lo, own_hi))
 
 
+def _needs_host_hop(t: torch.Tensor, group=None) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def shard_rows(t: torch.Tensor, shard: FrameShard) -> torch.Tensor:
     """Rows of a per-frame tensor [N, ...] that make up this rank's local batch."""
     idx = torch.as_tensor(shard.index, device=t.device, dtype=torch.long)
@@ -85,7 +89,13 @@ def broadcast_conditioning(tensors: Dict[str, torch.Tensor], src: int = 0, group
     and dtype; they are filled in place."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         for name in sorted(tensors):
-            dist.broadcast(tensors[name], src=src, group=group)
+            t = tensors[name]
+            if _needs_host_hop(t, group):          # gloo with device tensors (1-GPU development mode)
+                h = t.cpu()
+                dist.broadcast(h, src=src, group=group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src, group=group)
     return tensors
 
 
@@ -101,8 +111,14 @@ def gather_owned(local: torch.Tensor, shard: FrameShard, group=None) -> torch.Te
     mx = max(b - a for a, b in parts)
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: own.shape[0]] = own
-    out = [torch.empty_like(pad) for _ in range(shard.world_size)]
-    dist.all_gather(out, pad, group=group)
+    if _needs_host_hop(pad, group):
+        hp = pad.cpu()
+        hout = [torch.empty_like(hp) for _ in range(shard.world_size)]
+        dist.all_gather(hout, hp, group=group)
+        out = [o.to(pad.device) for o in hout]
+    else:
+        out = [torch.empty_like(pad) for _ in range(shard.world_size)]
+        dist.all_gather(out, pad, group=group)
     return torch.cat([o[: b - a] for o, (a, b) in zip(out, parts)], dim=0)
 
 

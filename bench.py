@@ -141,14 +141,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development aid: AID_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0 with gloo collectives, so the N>1 code
+    # path (sharding, broadcast, all_gather, max-over-ranks) can be exercised on a 1-GPU box
+    one_dev = os.environ.get("AID_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_dev else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     if args.gpus != world:
         if rank == 0:
             print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     import aid_amd
     from aid_amd import dist as adist
@@ -201,7 +208,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if one_dev else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert final.shape[0] == n_total and torch.isfinite(final.float()).all()
