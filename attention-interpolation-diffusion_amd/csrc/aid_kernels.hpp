@@ -21,6 +21,7 @@ struct GemmGroup {                        // passed by value as the kernel argum
     GemmDesc p[AID_GEMM_MAX_PROBLEMS];
     int32_t  tile_start[AID_GEMM_MAX_PROBLEMS + 1];   // prefix sums of block counts (filled by the launcher)
     int32_t  n_problems;
+    int32_t  interleave;                              // 1: every XCD gets a chunk of each problem (unequal K loops)
 };
 
 // picks the tile shape, fills g.tile_start and launches
