@@ -33,7 +33,7 @@ class AidGemmProblem(C.Structure):
         ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("bias", C.c_void_p),
         ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
         ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
-        ("batch", C.c_int32), ("_pad", C.c_int32),
+        ("batch", C.c_int32), ("scale", C.c_float),
         ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64),
     ]
 
@@ -50,7 +50,7 @@ class AidAttnArgs(C.Structure):
         ("mode", C.c_int32), ("fused", C.c_int32), ("begin", C.c_int32), ("end", C.c_int32),
         ("accumulate", C.c_int32), ("dtype", C.c_int32),
         ("softmax_scale", C.c_float), ("out_scale", C.c_float),
-        ("n_plain", C.c_int32), ("_pad", C.c_int32),
+        ("n_plain", C.c_int32), ("q_prescaled", C.c_int32),
     ]
 
 

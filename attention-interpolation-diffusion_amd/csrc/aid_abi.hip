@@ -182,6 +182,7 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
         d.m = q.m; d.n = q.n; d.k = q.k;
         d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc;
         d.batch = q.batch;
+        d.scale = q.scale == 0.f ? 1.f : q.scale;
         d.stride_a = q.stride_a; d.stride_b = q.stride_b; d.stride_c = q.stride_c;
     }
     double flops = 0, bytes = 0;
@@ -286,6 +287,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     pr[0].a = a.x;  pr[0].b = a.wq; pr[0].c = q;
     pr[0].m = a.n_frames * a.s; pr[0].n = a.c; pr[0].k = a.c;
     pr[0].lda = a.c; pr[0].ldb = a.c; pr[0].ldc = a.c; pr[0].batch = 1;
+    pr[0].scale = 1.4426950408889634f / sqrtf((float)d);      // softmax_scale * log2(e) folded into q before its rounding
     pr[1].a = e;    pr[1].b = a.wk; pr[1].c = k;
     pr[1].m = nctx * l; pr[1].n = a.c; pr[1].k = cc;
     pr[1].lda = cc; pr[1].ldb = cc; pr[1].ldc = a.c; pr[1].batch = 1;
@@ -318,6 +320,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     at.softmax_scale = 1.0f / sqrtf((float)d);
     at.out_scale = 1.0f;
     at.n_plain = a.n_plain;
+    at.q_prescaled = 1;
     rc = aid_attn_fwd(&at, stream);
     if (rc != AID_OK) return rc;
 

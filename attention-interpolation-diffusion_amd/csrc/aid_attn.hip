@@ -19,11 +19,21 @@
 //   The K tile is read with key bits 2<->3 swapped so the P registers a lane holds after the first
 //   product are exactly the 8 consecutive keys it must supply as B operand to the second one
 //   (no cross-lane shuffle of P).
-// Online softmax in the base-2 domain with a LAZY rescale: the running reference m of a row is only
-// raised (and O, l rescaled) when some row of the wave saw a score more than 2^8 above its
-// reference; otherwise P = 2^(s - m) simply exceeds 1 (<= 256, exact in fp16/bf16/fp32 floating
-// point), which removes the 32-accumulator rescale from almost every tile.  The decision is
-// wave-uniform and taken before the tile's P is formed.
+// The kernel is VALU-ISSUE bound, not MFMA bound (PMC: 168 VALU per 16 MFMA per wave-tile in the first
+// version, profiles/r01_attn_notes.txt), so all the LINEAR arithmetic of the online softmax is pushed
+// into the matrix pipe:
+//   * Q arrives pre-multiplied by softmax_scale*log2(e) (folded into the q-projection GEMM epilogue, before
+//     its single rounding), and the accumulator of the first product is INITIALISED to -m (the row's
+//     reference, lane-local because a lane owns one query column): the MFMA result IS the exponent
+//     argument x = s*c - m — no per-score FMA;
+//   * the row sums come out of the second product: V^T carries a row of ones (a spare padded row for d = 40 /
+//     80, one extra 32-row block fed from a constant register fragment for d = 64 / 160), so l is a row of
+//     the O^T accumulator — no per-score add, and the rescale covers it automatically;
+//   * the reference m is LAZY: it is set from the first tile and only raised when some exponent argument
+//     of the wave exceeds the head-room of the storage type (2^15 for fp16, 2^60 for bf16); P = 2^x may exceed
+//     1, which is exact in floating point.  The check is one v_max3 chain + a wave-uniform branch; the slow
+//     path (rare) rescales O and shifts the tile's x in registers.
+// What is left per score on the VALU is one v_exp_f32 and half a v_cvt_pk.
 // K / Vt tiles go global -> registers -> LDS (issued before the tile's compute, written after it,
 // two LDS buffers, one barrier per tile); the loads are branch-free (edge rows are clamped, never
 // predicated).  LDS rows are padded by 16 B (odd 16-B stride): all fragment reads are bank-conflict
@@ -46,7 +56,6 @@ namespace aid {
 
 constexpr int KT = 64;                  // keys per tile
 constexpr int VLD = KT + 8;             // padded Vt tile row (elements)
-constexpr float LAZY_TAU = 8.0f;        // log2 head-room before a row's reference max is raised
 
 struct AttnKParams {
     AidAttnArgs a;
@@ -56,10 +65,14 @@ struct AttnKParams {
 
 __host__ __device__ constexpr bool attn_prefetch(int d, int nw) { return nw == 4 && d <= 80; }
 
-template <int NDB>
+// Online-softmax state of one wave: reference m (scaled log2 domain, per query = per lane), O^T blocks, and —
+// when the head dim leaves no spare padded row — the extra block whose row 0 accumulates the row sums.
+template <int NDB, bool XL>
 struct OState {
-    float  m, l;
+    float  m;
+    bool   fresh;                       // no tile processed yet: the first tile sets the reference
     f32x16 o[NDB];
+    f32x16 ol[XL ? 1 : 1];              // only used when XL
 };
 
 typedef __amdgpu_buffer_rsrc_t Rsrc;
@@ -91,6 +104,13 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     // registers fit beside the accumulators; otherwise stage synchronously through one buffer.
     constexpr bool PREFETCH = attn_prefetch(D, NW);
     constexpr int NBUF = PREFETCH ? 2 : 1;
+    // row of ones in V^T -> the row sums l come out of the second MFMA as a row of O^T.  A spare padded row
+    // (index D) exists for d = 40 / 80; d = 64 / 160 use one eXtra 32-row block fed from a constant fragment.
+    constexpr bool XL = (D == DV);
+    constexpr int LBLK = D / 32, LREG = ((D % 32) / 8) * 4;     // (block, register) of row D at lanes hi == 0
+    static_assert(XL || ((D % 32) % 8 == 0 && (D % 32) < 32), "spare row must sit at a register boundary");
+    // head-room (log2) of P = 2^x in the storage type before the row reference has to be raised
+    constexpr float XTH = sizeof(T) == 2 && std::is_same<T, f16>::value ? 15.0f : 60.0f;
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
     static_assert((KLD / 8) % 2 == 1 && (VLD / 8) % 2 == 1, "LDS row stride must be an odd number of 16-B slots");
 
@@ -111,6 +131,10 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     // zero both LDS buffers once: pad columns / pad rows are never staged and must be finite
     for (int i = tid; i < NBUF * (KT * KLD + DV * VLD) / 8; i += NT)
         reinterpret_cast<T8*>(Ks)[i] = zero8<T>();
+    if (!XL) {                                          // the ones row (never touched by the staging, which writes rows < D)
+        __syncthreads();
+        for (int i = tid; i < NBUF * KT; i += NT) Vs[(i / KT) * DV * VLD + D * VLD + (i % KT)] = (T)1.0f;
+    }
 
     // ---- Q fragments (B operand of the swapped product), straight from global -------------
     T8 qf[NQK];
@@ -121,8 +145,18 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         for (int ks = 0; ks < NQK; ++ks) {
             const int col = ks * 16 + hi * 8;
             qf[ks] = (col < D) ? *reinterpret_cast<const T8*>(qrow + col) : zero8<T>();
+            if (!a.q_prescaled) {                       // generic callers: fold softmax_scale*log2(e) into Q here (one
+                f32x8 t = up8<T>(qf[ks]);               // extra rounding; the processor path does it in the GEMM epilogue)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] *= p.c2;
+                qf[ks] = cvt8<T>(t);
+            }
         }
     }
+    // constant A fragment of the row-sum block (XL): row 0 = ones, every other row zero
+    T8 onesf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) onesf[e] = (l31 == 0) ? (T)1.0f : (T)0.0f;
     __syncthreads();
 
     const int kvf = a.kv_map ? a.kv_map[fr] : fr;
@@ -131,7 +165,6 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)(h * D) * a.ldvt;
     const int L = a.l;
     const int Lc8 = ((L - 1) >> 3) << 3;                // first key of the last 8-key chunk holding a valid key
-    const float c2 = p.c2;
     // key bits 2<->3 swapped: MFMA row i of the score block reads LDS key row pi(i)
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
 
@@ -150,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 
     // ---- one segment of keys: online-softmax update of `st` ----------------------------------
     // k0/v0: frame base pointers (already offset to head h)
-    auto run = [&](OState<NDB>& st, const T* k0, const T* v0) __attribute__((always_inline)) {
+    auto run = [&](OState<NDB, XL>& st, const T* k0, const T* v0) __attribute__((always_inline)) {
         T8 rk[PREFETCH ? NKC : 1], rv[PREFETCH ? NVC : 1];
         // buffer descriptors of the segment's K / Vt (wave-uniform); per-lane byte offsets are 32-bit and the
         // tile advance goes into the scalar offset, so a full tile costs no address VALU at all
@@ -255,21 +288,24 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         auto tile = [&](int buf, int key0, auto full_tag) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
             const int nb = FULL ? 2 : ((L - key0 > 32) ? 2 : 1);   // 32-key blocks with any valid key
-            // S^T = K Q^T
+            // x^T = K Q'^T - m : the accumulator starts at -m, so the MFMA result is the exponent argument
+            f32x16 cneg;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cneg[r] = -st.m;
             f32x16 sc[2];
             const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 if (FULL || b < nb) {
-                    sc[b] = mfma32(*reinterpret_cast<const T8*>(kt + b * 32 * KLD), qf[0], zero16());
+                    sc[b] = mfma32(*reinterpret_cast<const T8*>(kt + b * 32 * KLD), qf[0], cneg);
 #pragma unroll
                     for (int ks = 1; ks < NQK; ++ks)
                         sc[b] = mfma32(*reinterpret_cast<const T8*>(kt + b * 32 * KLD + ks * 16), qf[ks], sc[b]);
                 } else {
-                    sc[b] = zero16();
+                    sc[b] = cneg;
                 }
             }
-            // lane (q, hi): sc[b][r] is the score of key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
+            // lane (q, hi): sc[b][r] belongs to key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
             if (!FULL) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
@@ -277,29 +313,31 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     for (int r = 0; r < 16; ++r)
                         if (key0 + 32 * b + 16 * (r >> 3) + 8 * hi + (r & 7) >= L) sc[b][r] = -1e30f;
             }
-            // row max of the tile (in-lane tree + partner half)
-            float mx[8];
+            // head-room check: one v_max3 chain over this lane's 32 arguments, wave-uniform decision
+            float xm = fmaxf(sc[0][0], sc[0][1]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                mx[i] = fmaxf(fmaxf(sc[i >> 2][(i & 3) * 4], sc[i >> 2][(i & 3) * 4 + 1]),
-                              fmaxf(sc[i >> 2][(i & 3) * 4 + 2], sc[i >> 2][(i & 3) * 4 + 3]));
-            float tmax = fmaxf(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])), fmaxf(fmaxf(mx[4], mx[5]), fmaxf(mx[6], mx[7])));
-            tmax = max_halves(tmax);
-            // lazy rescale: raise the reference only when some row of the wave out-grew its head-room
-            if (__any((tmax - st.m) * c2 > LAZY_TAU)) {
-                const float m_new = fmaxf(st.m, tmax);
-                const float alpha = __builtin_amdgcn_exp2f((st.m - m_new) * c2);
-                st.m = m_new;
-                st.l *= alpha;
+            for (int i = 1; i < 16; ++i) xm = fmaxf(fmaxf(xm, sc[i >> 3][(2 * i) & 15]), sc[i >> 3][(2 * i + 1) & 15]);
+            if (st.fresh || __any(xm > XTH)) {
+                // slow path (first tile of a row, or a score out-grew the head-room): move the reference to the
+                // row maximum, rescale O (its ones-row = l included) and shift this tile's arguments in registers
+                const float rowmax = max_halves(xm);
+                const float shift = st.fresh ? rowmax : fmaxf(rowmax, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-shift);
+                st.m += shift;
+                st.fresh = false;
 #pragma unroll
                 for (int d = 0; d < NDB; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) st.o[d][r] *= alpha;
+                if (XL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st.ol[0][r] *= alpha;
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[b][r] -= shift;
             }
-            // scalar fp32 VALU on purpose: the packed forms (v_pk_fma_f32 / v_pk_add_f32) were measured 8 % slower
-            // here (profiles/r01_attn_notes.txt) — they issue at half rate beside the MFMAs
-            const float mc = st.m * c2;
-            float ps[4] = {0.f, 0.f, 0.f, 0.f};                     // independent row-sum chains
             T8 pf[4];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -307,14 +345,10 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 for (int u = 0; u < 2; ++u) {
                     f32x8 pv;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pv[e] = __builtin_amdgcn_exp2f(fmaf(sc[b][8 * u + e], c2, -mc));
-                        ps[e & 3] += pv[e];
-                    }
+                    for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
                     pf[2 * b + u] = cvt8<T>(pv);
                 }
-            st.l += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            // O^T += Vt P^T
+            // O^T += Vt P^T   (the ones row / ones block accumulates the row sums)
             const T* vt = Vs + buf * DV * VLD + l31 * VLD + hi * 8;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -322,6 +356,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 #pragma unroll
                     for (int d = 0; d < NDB; ++d)
                         st.o[d] = mfma32(*reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16), pf[kk], st.o[d]);
+                    if (XL) st.ol[0] = mfma32(onesf, pf[kk], st.ol[0]);
                 }
             }
         };
@@ -363,11 +398,18 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         }
     };
 
-    auto init = [&](OState<NDB>& st) {
-        st.m = -1e30f;
-        st.l = 0.f;
+    auto init = [&](OState<NDB, XL>& st) {
+        st.m = 0.f;
+        st.fresh = true;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) st.o[d] = zero16();
+        st.ol[0] = zero16();
+    };
+    // 1 / (row sum) of a finished state: the sum sits in the ones-row of O^T at the lanes of half 0
+    auto inv_l = [&](const OState<NDB, XL>& st) __attribute__((always_inline)) {
+        const float lv = XL ? st.ol[0][0] : st.o[LBLK][LREG];
+        const float partner = other_half(lv);          // executed by every lane (cross-half permute)
+        return 1.f / (hi ? partner : lv);
     };
 
     const T* k_own = Kg + (int64_t)kvf * a.k_fs;
@@ -377,20 +419,20 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const T* k_end = Kg + (int64_t)a.end * a.k_fs;
     const T* v_end = Vg + (int64_t)a.end * a.vt_fs;
 
-    OState<NDB> st;
+    OState<NDB, XL> st;
     init(st);
     f32x16 res[NDB];
 
     if (MODE == AID_MODE_PLAIN) {
         run(st, k_own, v_own);
-        const float inv = 1.f / sum_halves(st.l);
+        const float inv = inv_l(st);
 #pragma unroll
         for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
     } else if (cf < 0.f) {
         // negative coefficient = this frame is PLAIN inside an INNER / OUTER launch (the unconditional half of a
         // classifier-free-guidance batch rides in the same call)
         run(st, k_own, v_own);
-        const float inv = 1.f / sum_halves(st.l);
+        const float inv = inv_l(st);
 #pragma unroll
         for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
     } else if (MODE == AID_MODE_INNER) {
@@ -401,7 +443,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         else if (cf == 1.f) run(st, k_end, v_end);
         else                run(st, reinterpret_cast<const T*>(a.k2) + h * D + (int64_t)fr * a.k_fs,
                                 reinterpret_cast<const T*>(a.vt2) + (int64_t)(h * D) * a.ldvt + (int64_t)fr * a.vt_fs);
-        const float inv = 1.f / sum_halves(st.l);
+        const float inv = inv_l(st);
 #pragma unroll
         for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
     } else {
@@ -409,15 +451,15 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 #pragma unroll
         for (int d = 0; d < NDB; ++d) res[d] = zero16();
         if (cf != 1.f) {                                    // begin side, weight (1 - c)
-            OState<NDB> sb = st;
+            OState<NDB, XL> sb = st;
             run(sb, k_beg, v_beg);
-            const float w = (1.f - cf) / sum_halves(sb.l);
+            const float w = (1.f - cf) * inv_l(sb);
 #pragma unroll
             for (int d = 0; d < NDB; ++d) res[d] = sb.o[d] * w;
         }
         if (cf != 0.f) {                                    // end side, weight c
             run(st, k_end, v_end);
-            const float w = cf / sum_halves(st.l);
+            const float w = cf * inv_l(st);
 #pragma unroll
             for (int d = 0; d < NDB; ++d) res[d] += st.o[d] * w;
         }

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_kernel(const GemmGroup g
                 if (n >= P.n) continue;
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[in][im][gq * 4 + e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[in][im][gq * 4 + e] * P.scale;
                 if (bias) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -362,7 +362,7 @@ struct Engine {
                 for (int im = 0; im < MB; ++im) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[in][im][gq * 4 + e] + bv[e];
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[in][im][gq * 4 + e], P.scale, bv[e]);
                     *reinterpret_cast<T4*>(Cs + (wm + im * 32 + l31) * CLD + nl) = cvt4<T>(v);
                 }
             }

@@ -13,7 +13,8 @@ struct GemmDesc {
     const void* bias;
     int32_t m, n, k;
     int32_t lda, ldb, ldc;
-    int32_t batch, _pad;
+    int32_t batch;
+    float   scale;                                    // C = scale * A B^T + bias
     int64_t stride_a, stride_b, stride_c;
 };
 

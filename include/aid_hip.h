@@ -71,7 +71,7 @@ typedef struct AidGemmProblem {
     int32_t     m, n, k;
     int32_t     lda, ldb, ldc; /* in elements */
     int32_t     batch;         /* >= 1 */
-    int32_t     _pad;
+    float       scale;         /* C = scale * (A B^T) + bias; 0 means 1 (zero-initialised structs)  */
     int64_t     stride_a, stride_b, stride_c;   /* per-batch strides in elements (0 = shared) */
 } AidGemmProblem;
 
@@ -121,7 +121,8 @@ typedef struct AidAttnArgs {
     float   softmax_scale;       /* d^-0.5 for diffusers Attention                           */
     float   out_scale;
     int32_t n_plain;             /* frames with a negative coefficient (profiling accounting) */
-    int32_t _pad;
+    int32_t q_prescaled;         /* 1: q already holds q * softmax_scale * log2(e) (fold it into the     */
+                                 /* q-projection via AidGemmProblem.scale); 0: the kernel scales Q itself */
 } AidAttnArgs;
 
 int aid_attn_fwd(const AidAttnArgs* args /* host */, void* stream);
