@@ -71,6 +71,18 @@ def make_inputs(unet, n_frames, dtype, device, seed=1002):
     return xs, cond, uncond
 
 
+def recorded_traffic(model, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC collection (profiles/r01_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, gfx950 x2 correction
+    on FETCH_SIZE applied).  PMC counters cannot be collected from inside this process; null if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["models"][model][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def roofline_pass(loop, aid_amd):
     """HIP-event timing (on the launch stream) of every kernel of one AID step + one plain step."""
     lib = aid_amd._lib.load()
@@ -242,7 +254,8 @@ def main():
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         result["roofline"] = {
             "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-            "traffic": None, "kernel": dom, "launches": d["launches"],
+            "traffic": recorded_traffic(model, dom), "kernel": dom, "launches": d["launches"],
+            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
             "avg_launch_us": d["ms"] * 1e3 / d["launches"], "avg_launch_gflop": d["flops"] / d["launches"] / 1e9,
             "note": "algorithmic flops (SURVEY.md §8d) / HIP-event time on the launch stream, 1 AID step + 1 plain step",
             "kernels": {k: {"ms": round(v["ms"], 4), "launches": v["launches"],
