@@ -12,7 +12,7 @@ import subprocess
 from typing import Optional
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libaid_hip.so")
+LIB_PATH = os.environ.get("AID_LIB_PATH") or os.path.join(PKG_DIR, "libaid_hip.so")   # override: development A/B builds
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 AID_ABI_VERSION = 1

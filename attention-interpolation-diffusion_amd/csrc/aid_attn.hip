@@ -49,6 +49,10 @@
 
 #include <type_traits>
 
+#ifndef AID_ABL
+#define AID_ABL 0      // development only: timing ablations of the tile loop (tools/ablate.sh); 0 = product
+#endif
+
 #include "aid_common.hpp"
 #include "aid_kernels.hpp"
 
@@ -294,6 +298,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             for (int r = 0; r < 16; ++r) cneg[r] = -st.m;
             f32x16 sc[2];
             const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
+            // k-step outer, key-block inner: consecutive MFMAs go to DIFFERENT accumulators, so the dependent
+            // chain of one block never stalls the matrix pipe (the block-outer order measured ~45 % of the tile time)
+#if AID_ABL == 2
+            sc[0] = cneg; sc[1] = cneg;
+#elif AID_ABL == 6                       // block-outer order (the original): one dependent chain after the other
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 if (FULL || b < nb) {
@@ -305,6 +314,15 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     sc[b] = cneg;
                 }
             }
+#else
+            sc[0] = mfma32(*reinterpret_cast<const T8*>(kt), qf[0], cneg);
+            sc[1] = (FULL || nb > 1) ? mfma32(*reinterpret_cast<const T8*>(kt + 32 * KLD), qf[0], cneg) : cneg;
+#pragma unroll
+            for (int ks = 1; ks < NQK; ++ks) {
+                sc[0] = mfma32(*reinterpret_cast<const T8*>(kt + ks * 16), qf[ks], sc[0]);
+                if (FULL || nb > 1) sc[1] = mfma32(*reinterpret_cast<const T8*>(kt + 32 * KLD + ks * 16), qf[ks], sc[1]);
+            }
+#endif
             // lane (q, hi): sc[b][r] belongs to key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
             if (!FULL) {
 #pragma unroll
@@ -345,14 +363,25 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 for (int u = 0; u < 2; ++u) {
                     f32x8 pv;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
+                    for (int e = 0; e < 8; ++e) {
+#if AID_ABL == 1
+                        pv[e] = sc[b][8 * u + e];
+#else
+                        pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
+#endif
+                    }
                     pf[2 * b + u] = cvt8<T>(pv);
                 }
             // O^T += Vt P^T   (the ones row / ones block accumulates the row sums)
             const T* vt = Vs + buf * DV * VLD + l31 * VLD + hi * 8;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
+#if AID_ABL == 3
+                asm volatile("" ::"v"(pf[kk]));
+                if (false) {
+#else
                 if (FULL || kk < 2 * nb) {
+#endif
 #pragma unroll
                     for (int d = 0; d < NDB; ++d)
                         st.o[d] = mfma32(*reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16), pf[kk], st.o[d]);
@@ -373,7 +402,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         int t = 0;
         for (; t < nfull; ++t) {                        // tiles with all 64 keys valid: no masks, no edge logic
             const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
+#if AID_ABL == 4
+            if (false) {
+#else
             if (PREFETCH) {
+#endif
                 if (t + 1 < nfull)   stage_load(key0 + KT, std::true_type{});
                 else if (t + 1 < nt) stage_load(key0 + KT, std::false_type{});
             } else {
@@ -381,11 +414,17 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 __syncthreads();
             }
             tile(buf, key0, std::true_type{});
+#if AID_ABL == 4
+            if (false) {
+#else
             if (PREFETCH) {
+#endif
                 if (t + 1 < nfull)   stage_write(buf ^ 1, key0 + KT, std::true_type{});
                 else if (t + 1 < nt) stage_write(buf ^ 1, key0 + KT, std::false_type{});
             }
+#if AID_ABL != 5
             __syncthreads();
+#endif
         }
         if (t < nt) {                                   // ragged last tile
             const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
