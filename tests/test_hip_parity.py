@@ -343,3 +343,60 @@ def test_batched_cfg_equals_two_separate_calls(dtype, kind, cross):
     proc.plain_tail = 0
     with pytest.raises(RuntimeError, match="must match the size"):
         proc(attn, torch.cat([xc, xu]))
+
+
+# ------------------------------------------------------------------------------------------------
+# randomized shapes (seeded): every mode, ragged S / L, shard-style end points, both dtypes
+# ------------------------------------------------------------------------------------------------
+def test_randomized_shapes_all_modes():
+    rs = np.random.RandomState(20240928)
+    for it in range(40):
+        d = int(rs.choice([40, 64, 80, 160]))
+        h = int(rs.randint(1, 4))
+        n = int(rs.randint(2, 9))
+        s = int(rs.choice([1, 7, 31, 32, 33, 64, 127, 129, 200, 257]))
+        l = int(rs.choice([1, 5, 63, 64, 65, 77, 128, 150, 193]))
+        dtype = DTYPES[it % 2]
+        mode, fused = MODES[int(rs.randint(0, len(MODES)))]
+        begin, end = (0, n - 1) if rs.rand() < 0.5 else (int(rs.randint(0, n)), int(rs.randint(0, n)))
+        q, k, v, vt = _core_inputs(n, s, l, h, d, dtype, seed=1000 + it)
+        coef = torch.from_numpy(rs.rand(n).astype(np.float32))
+        coef[begin], coef[end] = 0.0, 1.0
+        if begin == end:
+            coef[begin] = 0.0
+        o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused, coef=coef.to(DEV),
+                         begin=begin, end=end)
+        ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, mode, fused, coef.numpy(), begin=begin, end=end)
+        err = rel_l2(to_np64(o), ref)
+        assert err < TOL[dtype], (it, d, h, n, s, l, mode, fused, begin, end, err)
+
+
+@pytest.mark.parametrize("tokens", [4, 16])
+def test_ip_processors_at_sdxl_layer_shape(tokens):
+    """BASELINE configs[4] layer shape (SDXL S=1024, C=1280, H=20, Cc=2048, bf16), batch 3 = the per-rank
+    batch of the 8-frame / 8-GPU layout: outer-IP and scale-control vs the fp64 oracle."""
+    dtype = torch.bfloat16
+    s, c, h, cc, l = 1024, 1280, 20, 2048, 77
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(dtype)   # noqa: E731
+    inp = dict(x=mk(3, s, c), text=mk(3, l, cc), ip=mk(9, 1, tokens, cc), wq=mk(c, c, sc=c ** -0.5),
+               wk=mk(c, cc, sc=cc ** -0.5), wv=mk(c, cc, sc=cc ** -0.5), wo=mk(c, c, sc=c ** -0.5), bo=mk(c, sc=0.01),
+               wk_ip=mk(c, cc, sc=cc ** -0.5), wv_ip=mk(c, cc, sc=cc ** -0.5))
+    attn = aid_amd.AttnShim(c, h, cc, dtype=dtype, device=DEV)
+    ipa = aid_amd.IPAdapterShim(c, cc, num_tokens=tokens, scale=0.7, dtype=dtype, device=DEV)
+    with torch.no_grad():
+        for lin, key in ((attn.to_q, "wq"), (attn.to_k, "wk"), (attn.to_v, "wv"), (attn.to_out[0], "wo"),
+                         (ipa.to_k_ip[0], "wk_ip"), (ipa.to_v_ip[0], "wv_ip")):
+            lin.weight.copy_(inp[key])
+        attn.to_out[0].bias.copy_(inp["bo"])
+    n64 = {k_: to_np64(v_) for k_, v_ in inp.items()}
+    w = O.AttnWeights(n64["wq"], n64["wk"], n64["wv"], n64["wo"], n64["bo"], h)
+    ipw = O.IPWeights(n64["wk_ip"], n64["wv_ip"], 0.7, tokens)
+    ehs = (inp["text"].to(DEV), [inp["ip"].to(DEV)])
+    coef = torch.tensor([0.0, 0.4, 1.0]).to(dtype).float().numpy()
+    y = aid_amd.OuterInterpolatedIPAttnProcessor(t=0.4, is_fused=True, ip_attn=ipa)(attn, inp["x"].to(DEV), encoder_hidden_states=ehs)
+    ref = O.outer_ip_attention(n64["x"], n64["text"], n64["ip"], w, ipw, coef, True)
+    assert rel_l2(to_np64(y), ref) < TOL[dtype]
+    y2 = aid_amd.ScaleControlIPAttnProcessor(t=0.4, is_fused=True, ip_attn=ipa)(attn, inp["x"].to(DEV), encoder_hidden_states=ehs)
+    ref2 = O.scale_control_ip_attention(n64["x"], n64["text"], n64["ip"], w, ipw, coef, True, activated=True)
+    assert rel_l2(to_np64(y2), ref2) < TOL[dtype]
