@@ -132,9 +132,12 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const int h = lid / (p.nqb * a.n_frames);
     const int q0 = (qb * NW + wave) * 32;
 
-    // zero both LDS buffers once: pad columns / pad rows are never staged and must be finite
-    for (int i = tid; i < NBUF * (KT * KLD + DV * VLD) / 8; i += NT)
-        reinterpret_cast<T8*>(Ks)[i] = zero8<T>();
+    // zero both LDS buffers once where the head dim is padded (d = 40 / 80): pad columns of K / pad rows of V^T are
+    // never staged and must be finite.  d = 64 / 160 have no padding that a fragment read touches.
+    if (DK != D || DV != D) {
+        for (int i = tid; i < NBUF * (KT * KLD + DV * VLD) / 8; i += NT)
+            reinterpret_cast<T8*>(Ks)[i] = zero8<T>();
+    }
     if (!XL) {                                          // the ones row (never touched by the staging, which writes rows < D)
         __syncthreads();
         for (int i = tid; i < NBUF * KT; i += NT) Vs[(i / KT) * DV * VLD + D * VLD + (i % KT)] = (T)1.0f;
