@@ -8,7 +8,8 @@ the repository root (``import aid_amd``).
 Layout:  csrc/ (HIP kernels + C ABI, built to libaid_hip.so)  ·  _lib.py (ctypes binding)  ·
 ops.py (tensor-level entry points)  ·  processors.py (the reference's AttnProcessor classes)  ·
 interp.py (coefficients, slerp / lerp initialisation)  ·  attn_shim.py (diffusers stand-ins)  ·
-dist.py (frame sharding over RCCL)  ·  loop.py (denoising-loop harness).
+dist.py (frame sharding over RCCL)  ·  loop.py (denoising-loop harness)  ·  sequence.py (batch assembly of
+interpolate_single / N-frame interpolate).
 """
 from .interp import generate_beta_tensor, linear_interpolation, slerp, spherical_interpolation
 from .processors import (HipAttnProcessor, InnerInterpolatedAttnProcessor, InnerInterpolatedIPAttnProcessor,
@@ -16,7 +17,7 @@ from .processors import (HipAttnProcessor, InnerInterpolatedAttnProcessor, Inner
                          OuterInterpolatedIPAttnProcessor, ScaleControlIPAttnProcessor, activate_aid,
                          deactivate_aid, load_aid)
 from .attn_shim import AttnShim, AttnStackUNet, IPAdapterShim
-from . import ops, _lib
+from . import ops, _lib, sequence, loop, dist
 
 __all__ = [
     "generate_beta_tensor", "linear_interpolation", "slerp", "spherical_interpolation",
