@@ -470,9 +470,12 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         const float inv = inv_l(st);
 #pragma unroll
         for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
-    } else if (cf < 0.f) {
-        // negative coefficient = this frame is PLAIN inside an INNER / OUTER launch (the unconditional half of a
-        // classifier-free-guidance batch rides in the same call)
+    } else if (cf < 0.f || (a.fused && ((cf == 0.f && kvf == a.begin) || (cf == 1.f && kvf == a.end)))) {
+        // (1) negative coefficient = this frame is PLAIN inside an INNER / OUTER launch (the unconditional half of
+        //     a classifier-free-guidance batch rides in the same call);
+        // (2) a fused END-POINT frame: its second segment would be its own keys again ([K_0 ; K_0]) — duplicating
+        //     every key leaves softmax(QK^T)V unchanged (SURVEY.md §4 invariant), so one pass over the own keys is
+        //     the same result with half the work.
         run(st, k_own, v_own);
         const float inv = inv_l(st);
 #pragma unroll

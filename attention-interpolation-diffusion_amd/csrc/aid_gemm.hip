@@ -652,6 +652,9 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream) {
             case 12: return launch_pipe<T, 256, 256, 64, 2, 2, 4>(g, stream);   // 8 waves, 128x64 wave tiles, 128 KB
             case 13: return launch_pipe<T, 256, 128, 32, 4, 4, 2>(g, stream);   // BK 32, 4 stages (96 KB)
             case 14: return launch_pipe<T, 256, 128, 32, 6, 4, 2>(g, stream);   // BK 32, 6 stages (144 KB)
+            case 15: return launch_pipe<T, 128, 128, 64, 2, 1, 2>(g, stream);   // 2 waves, 128x64 wave tiles, 2 WG/CU
+            case 16: return launch_pipe<T, 256, 128, 64, 2, 2, 2>(g, stream);   // 4 waves, 128x64 wave tiles, 1 WG/CU
+            case 17: return launch_pipe<T, 128, 128, 64, 2, 2, 1>(g, stream);   // 2 waves, 64x128 wave tiles
             case 20: return launch_sk<T, 256, 128, 64, 3, 4, 2>(g, stream);     // stream-K, 256x128 tiles
             case 21: return launch_sk<T, 256, 256, 64, 2, 2, 4>(g, stream);     // stream-K, 256x256 tiles
             case 22: return launch_sk<T, 128, 128, 64, 2, 2, 4>(g, stream);     // stream-K, 128x128 tiles (1 WG/CU)
