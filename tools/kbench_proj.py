@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Grouped q/k/V^T projection launch and out-projection launch at every SD1.5 / SDXL level (batched CFG: 14 frames)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import aid_amd
+from aid_amd import ops
+dev = torch.device("cuda:0"); lib = aid_amd._lib.load()
+def timed(fn, iters=20):
+    fn(); fn(); torch.cuda.synchronize(); lib.aid_profile_begin()
+    for _ in range(iters): fn()
+    buf = (aid_amd._lib.AidProfileEntry * 512)(); n = lib.aid_profile_end(buf, 512)
+    return sum(e.ms for e in buf[:n]) / n * 1e3, sum(e.flops for e in buf[:n]) / n
+for tag, dt, s, c in (("sd15 L0", torch.float16, 4096, 320), ("sd15 L1", torch.float16, 1024, 640), ("sd15 L2", torch.float16, 256, 1280),
+                      ("sdxl L1", torch.bfloat16, 4096, 640), ("sdxl L2", torch.bfloat16, 1024, 1280)):
+    n = 14
+    x = torch.randn(n, s, c, device=dev).to(dt)
+    wq, wk, wv, wo = (torch.randn(c, c, device=dev).to(dt) for _ in range(4)); bo = torch.randn(c, device=dev).to(dt)
+    q = torch.empty_like(x); k = torch.empty_like(x); vt = torch.empty(n, c, s, device=dev, dtype=dt); y = torch.empty_like(x)
+    def qkv():
+        ops.gemm_nt([dict(a=x, b=wq, c=q, m=n * s, n=c, k=c, lda=c, ldb=c, ldc=c),
+                     dict(a=x, b=wk, c=k, m=n * s, n=c, k=c, lda=c, ldb=c, ldc=c),
+                     dict(a=wv, b=x, c=vt, m=c, n=s, k=c, lda=c, ldb=c, ldc=s, batch=n, stride_a=0, stride_b=s * c, stride_c=c * s)])
+    us, fl = timed(qkv); print(f"{tag} qkv  M={n*s} C={c}: {us:7.1f} us {fl/us/1e6:7.1f} TF/s  ideal-HBM {(4*n*s*c*2 + 3*c*c*2)/5e6:6.1f} us")
+    us, fl = timed(lambda: ops.linear(x, wo, bo, out=y)); print(f"{tag} out  M={n*s} C={c}: {us:7.1f} us {fl/us/1e6:7.1f} TF/s  ideal-HBM {(2*n*s*c*2)/5e6:6.1f} us")
