@@ -23,7 +23,7 @@ GEMM_MAX_PROBLEMS = 4
 # every symbol include/aid_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "aid_gemm_nt", "aid_attn_fwd", "aid_lerp_kv", "aid_processor_workspace_bytes", "aid_processor_fwd",
-    "aid_abi_version", "aid_strerror", "aid_last_attn_variant", "aid_device_info",
+    "aid_abi_version", "aid_strerror", "aid_last_attn_variant", "aid_last_gemm_variant", "aid_device_info",
     "aid_profile_begin", "aid_profile_end",
 )
 
@@ -100,6 +100,7 @@ def load() -> C.CDLL:
     lib.aid_strerror.restype = C.c_char_p
     lib.aid_strerror.argtypes = [C.c_int]
     lib.aid_last_attn_variant.restype = C.c_char_p
+    lib.aid_last_gemm_variant.restype = C.c_char_p
     lib.aid_device_info.restype = C.c_int
     lib.aid_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p]
     lib.aid_gemm_nt.restype = C.c_int

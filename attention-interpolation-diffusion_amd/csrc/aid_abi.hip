@@ -13,6 +13,7 @@ namespace {
 
 thread_local char g_err[256] = "";
 thread_local const char* g_variant = "";
+thread_local const char* g_gemm_variant = "";
 
 int fail_hip(hipError_t e, const char* where) {
     snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
@@ -125,6 +126,7 @@ const char* aid_strerror(int code) {
 }
 
 const char* aid_last_attn_variant(void) { return g_variant; }
+const char* aid_last_gemm_variant(void) { return g_gemm_variant; }
 
 int aid_device_info(int* n_cu, int* clock_khz, char* arch) {
     int dev = 0;
@@ -198,7 +200,7 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
     {
         ProfScope ps(static_cast<hipStream_t>(stream), dtype == AID_DTYPE_F16 ? "aid_gemm_nt<f16>" : "aid_gemm_nt<bf16>",
                      flops, bytes);
-        e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream));
+        e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream), &g_gemm_variant);
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_gemm_nt");
 }

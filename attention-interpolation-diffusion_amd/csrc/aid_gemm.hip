@@ -35,9 +35,8 @@ struct TileCoord {
 //    K = 1280 query projection) every XCD gets a contiguous chunk of EACH problem instead: with a plain
 //    concatenation all long-K tiles landed on two XCDs and set the launch time (105 -> 84 us measured).
 template <int BM, int BN>
-__device__ __forceinline__ TileCoord locate_tile(const GemmGroup& g) {
+__device__ __forceinline__ TileCoord locate_pos(const GemmGroup& g, int pos) {
     constexpr int NX = 8;
-    int pos = xcd_remap(blockIdx.x, gridDim.x);          // position in XCD-major order (bijective)
     int p = 0, local = 0;
     bool found = false;
     if (!g.interleave) {                                 // equal K loops: plain concatenation keeps ONE weight matrix per XCD
@@ -77,6 +76,11 @@ __device__ __forceinline__ TileCoord locate_tile(const GemmGroup& g) {
     return t;
 }
 
+template <int BM, int BN>
+__device__ __forceinline__ TileCoord locate_tile(const GemmGroup& g, int idx, int count) {
+    return locate_pos<BM, BN>(g, xcd_remap(idx, count));     // position in XCD-major order (bijective)
+}
+
 // ------------------------------------------------------------------------------------------------
 // edge kernel (ragged k)
 // ------------------------------------------------------------------------------------------------
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_kernel(const GemmGroup g
     T* As = reinterpret_cast<T*>(smem_raw);                 // [2][GBM][GLD]
     T* Bs = As + 2 * GBM * GLD;                             // [2][GBN][GLD]
 
-    const TileCoord tc = locate_tile<GBM, GBN>(g);
+    const TileCoord tc = locate_tile<GBM, GBN>(g, blockIdx.x, gridDim.x);
     const GemmDesc& P = g.p[tc.p];
     const int m0 = tc.m0, n0 = tc.n0;
     const T* __restrict__ A = reinterpret_cast<const T*>(P.a) + (int64_t)tc.batch * P.stride_a;
@@ -204,8 +208,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // Everything one workgroup needs to produce (part of) one BM x BN output tile: DMA addressing, the pipelined
-// MAC loop over a range of K tiles, the LDS-staged store, and the fp32 partial-tile exchange used by the
-// stream-K kernel.  All members are force-inlined; the accumulators live in registers.
+// MAC loop over a range of K tiles, the LDS-staged store.  All members are force-inlined; the accumulators live in registers.
 template <typename T, int BM, int BN, int BK, int NS, int WM, int WN>
 struct Engine {
     typedef typename Vec<T>::v8 T8;
@@ -386,43 +389,223 @@ struct Engine {
             }
         }
     }
+};
 
-    // fp32 partial tile <-> global scratch, lane-linear (16 B per lane, 1 KiB per wave-instruction); the reader
-    // is the same lane of the same wave index in another workgroup, so no layout translation is needed
-    __device__ __forceinline__ void write_partial(float* slot) {
-        f32x4* dst = reinterpret_cast<f32x4*>(slot) + (size_t)wave * (NB * MB * 4) * 64 + lane;
+// ---- 256 x 256 tile, two wave groups in ping-pong ---------------------------------------------------------
+// 8 waves as 2 (m) x 4 (n), wave tile 128 x 64 = 4 x 2 MFMA blocks.  The four waves with wr = 0 and the four
+// with wr = 1 (one of each per SIMD) run the same program ONE BARRIER APART: a K tile is two phases, a phase is
+// [fragment reads | barrier | 16 MFMAs on one half (64 x 64) of the wave tile, 4 DMA issues in between | barrier],
+// so while one group's MFMAs occupy the matrix pipes the other group's ds_reads use the LDS.  (The lock-step loop of Engine::mac leaves the matrix pipe idle during every read burst: 50 %
+// MFMA-busy at 256 x 256, LDS-bound at 128 x 128 — profiles/r01_gemm_variants.txt.)
+//   LDS: 2 parities x [A0 A1 B0 B1] half-tiles of 128 rows x 128 B.  A half h holds tile rows with bit 6 == h
+//   (the wave's blocks 2h, 2h+1), B half j the columns with bit 5 == j (the wave's block j).
+//   DMA stream in read order, half-tiles of 2 instructions per wave:  item s = 4 kt + q, q: 0 = B0, 1 = B1,
+//   2 = A0, 3 = A1;  phase P of K tile kt reads  P0: B0, B1, A0   P1: A1  and issues items 4 kt + 2 P + 6, + 7 between
+//   its MFMAs (6 items of lead).  The READ slot ends with a counted vmcnt that retires what the NEXT phase reads,
+//   followed by the barrier, so every wave's part of a half-tile is both landed and barrier-published before
+//   anybody reads it; a buffer is refilled >= 2 slots after the lgkmcnt that completed its last read.
+template <typename T>
+struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
+    typedef Engine<T, 256, 256, 64, 2, 2, 4> Base;
+    typedef typename Vec<T>::v8 T8;
+    static constexpr int HALF = 128 * 128;          // bytes per half-tile
+    static constexpr int STG = 4 * HALF;            // one parity
+    static constexpr size_t SMEM = Base::SMEM;
+    using Base::smem; using Base::tid; using Base::lane; using Base::wave; using Base::wm; using Base::wn;
+    using Base::l31; using Base::hi; using Base::aoff; using Base::boff; using Base::ax; using Base::bx;
+    using Base::asrc; using Base::bsrc; using Base::acc;
+    int wr;
+
+    static __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
+
+    __device__ __forceinline__ void init(char* smem_) {
+        smem = smem_;
+        tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        wr = wave >> 2;
+        wm = wr * 128;
+        wn = (wave & 3) * 64;
+        l31 = lane & 31;
+        hi = lane >> 5;
 #pragma unroll
-        for (int in = 0; in < NB; ++in)
-#pragma unroll
-            for (int im = 0; im < MB; ++im)
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[in][im][gq * 4 + e];
-                    dst[((in * MB + im) * 4 + gq) * 64] = v;
-                }
+        for (int e = 0; e < 2; ++e) {
+            const int lr = wr * 64 + e * 32 + l31;      // row inside an A half-tile
+            aoff[e] = lr * 128;
+            ax[e] = hi ^ swz(lr);
+        }
+        const int lb = (wave & 3) * 32 + l31;           // row inside a B half-tile
+        boff[0] = 2 * HALF + lb * 128;
+        bx[0] = hi ^ swz(lb);
     }
-    __device__ __forceinline__ void add_partial(const float* slot) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(slot) + (size_t)wave * (NB * MB * 4) * 64 + lane;
+
+    __device__ __forceinline__ void set_tile(const GemmDesc& P, const T* A, const T* B, int m0, int n0) {
 #pragma unroll
-        for (int in = 0; in < NB; ++in)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int im = 0; im < MB; ++im)
+            for (int j = 0; j < 2; ++j) {
+                const int lrow = 8 * (2 * wave + j) + (lane >> 3);
+                const int c = (lane & 7) ^ swz(lrow);
+                const int ra = (lrow >> 6) * 128 + h * 64 + (lrow & 63);
+                const int cb = (lrow >> 5) * 64 + h * 32 + (lrow & 31);
+                asrc[h * 2 + j] = A + (int64_t)min(m0 + ra, P.m - 1) * P.lda + c * 8;
+                bsrc[h * 2 + j] = B + (int64_t)min(n0 + cb, P.n - 1) * P.ldb + c * 8;
+            }
+    }
+
+    // DMA j (0 / 1) of half-tile Q: 0 = B0, 1 = B1, 2 = A0, 3 = A1
+    template <int Q>
+    __device__ __forceinline__ void dma_one(int parity, int k0, int j) {
+        constexpr bool IS_A = Q >= 2;
+        constexpr int H = Q & 1;
+        char* dst = smem + parity * STG + (IS_A ? 0 : 2 * HALF) + H * HALF + wave * 2048 + j * 1024;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)((IS_A ? asrc[H * 2 + j] : bsrc[H * 2 + j]) + k0),
+            (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+
+    static constexpr int E = 6;             // items of lead; a buffer is refilled >= 1 phase after its last read
+    template <int S>
+    __device__ __forceinline__ void issue_first(int kb, int nk) {        // prologue: items 0 .. E - 1
+        if ((S >> 2) < nk) {
+            dma_one<(S & 3)>((S >> 2) & 1, (kb + (S >> 2)) * 64, 0);
+            dma_one<(S & 3)>((S >> 2) & 1, (kb + (S >> 2)) * 64, 1);
+        }
+        if constexpr (S + 1 < E) issue_first<S + 1>(kb, nk);
+    }
+    // MFMA slot of phase P (0 / 1) of K tile kt issues items 4 kt + 2 P + E and + E + 1, one DMA at a time (i = 0..3)
+    template <int P>
+    __device__ __forceinline__ void issue(int kt, int kb, int nk, int i) {
+        constexpr int S0 = 2 * P + E;
+        const int s = S0 + (i >> 1);
+        const int t = kt + (s >> 2);
+        if (t < nk) {
+            if ((S0 & 3) == 2) {            // items A0, A1 of one tile
+                if (i < 2) dma_one<2>(t & 1, (kb + t) * 64, i & 1);
+                else       dma_one<3>(t & 1, (kb + t) * 64, i & 1);
+            } else {                        // items B0, B1
+                if (i < 2) dma_one<0>(t & 1, (kb + t) * 64, i & 1);
+                else       dma_one<1>(t & 1, (kb + t) * 64, i & 1);
+            }
+        }
+    }
+    // READ slot of phase P: block until what the NEXT phase reads has landed.  Newest item issued so far is
+    // 4 kt + 2 P + E - 1; P = 0 -> next reads A1(kt) = item 4 kt + 3; P = 1 -> next reads B0, B1, A0 of kt + 1 (<= 4 kt + 6)
+    template <int P>
+    __device__ __forceinline__ void retire(int kt, int nk) {
+        constexpr int NEWEST = 2 * P + E - 1;
+        constexpr int NEED = P == 0 ? 3 : 6;
+        static_assert(NEWEST >= NEED, "lead too short");
+        if (kt + (NEWEST >> 2) < nk) wait_vmcnt<2 * (NEWEST - NEED)>();
+        else                         wait_vmcnt<0>();
+    }
+
+    __device__ __forceinline__ void read_a(T8 (&fa)[2][4], const char* st, int h) {
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 v = src[((in * MB + im) * 4 + gq) * 64];
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[in][im][gq * 4 + e] += v[e];
-                }
+            for (int ks = 0; ks < 4; ++ks)
+                fa[e][ks] = *reinterpret_cast<const T8*>(st + h * HALF + aoff[e] + (((2 * ks) ^ ax[e]) << 4));
+    }
+    __device__ __forceinline__ void read_b(T8 (&fb)[2][4], const char* st) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fb[j][ks] = *reinterpret_cast<const T8*>(st + boff[0] + j * HALF + (((2 * ks) ^ bx[0]) << 4));
+    }
+    // MFMA slot of phase P: acc[0..1][2P .. 2P+1] += B blocks x A blocks of half P; 16 MFMAs on 4 independent
+    // accumulators with the phase's four DMAs in between
+    template <int P>
+    __device__ __forceinline__ void half(const T8 (&fb)[2][4], const T8 (&fa)[2][4], int kt, int kb, int nk) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ks = i >> 2, in = (i >> 1) & 1, e = i & 1;
+            acc[in][2 * P + e] = mfma32(fb[in][ks], fa[e][ks], acc[in][2 * P + e]);
+            if (i == 2 || i == 5 || i == 8 || i == 11) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue<P>(kt, kb, nk, (i - 2) / 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    static __device__ __forceinline__ void slot() {          // slot boundary: nothing moves across
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // Precondition: no VMEM operation of this wave outstanding, nobody still reads the LDS.
+    __device__ __forceinline__ void mac(int kb, int ke) {
+        const int nk = ke - kb;
+        issue_first<0>(kb, nk);
+        if (nk >= 2) wait_vmcnt<2 * (E - 3)>();             // B0, B1, A0 of the first tile landed
+        else         wait_vmcnt<0>();
+        slot();
+        if (wr == 1) slot();                // the second group runs one barrier behind
+        T8 fa[2][4], fb[2][4];
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* st = smem + (kt & 1) * STG;
+            read_b(fb, st);
+            read_a(fa, st, 0);
+            retire<0>(kt, nk);
+            slot();
+            half<0>(fb, fa, kt, kb, nk);
+            slot();
+            read_a(fa, st, 1);
+            retire<1>(kt, nk);
+            slot();
+            half<1>(fb, fa, kt, kb, nk);
+            slot();
+        }
+        if (wr == 0) slot();
+        wait_vmcnt<0>();
+        __syncthreads();                    // everyone is done reading the ring
     }
 };
+
+template <typename T>
+__global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, const int n_big) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int b = blockIdx.x;
+    if (b < n_big) {
+        const TileCoord tc = locate_pos<256, 256>(g, xcd_remap(b, n_big));
+        const GemmDesc& P = g.p[tc.p];
+        const T* A = reinterpret_cast<const T*>(P.a) + (int64_t)tc.batch * P.stride_a;
+        const T* B = reinterpret_cast<const T*>(P.b) + (int64_t)tc.batch * P.stride_b;
+        T* C = reinterpret_cast<T*>(P.c) + (int64_t)tc.batch * P.stride_c;
+        PingPong<T> e;
+        e.init(smem_raw);
+        e.set_tile(P, A, B, tc.m0, tc.n0);
+        e.zero_acc();
+        e.mac(0, P.k / 64);
+        e.store_tile(P, C, tc.m0, tc.n0);
+    } else {
+        const int u = b - n_big;                                   // n_big is a multiple of 8: u % 8 is still the XCD
+        const int n_rest = (gridDim.x - n_big) >> 2;
+        const int quad = u / n_rest, t = u - quad * n_rest;        // quadrant-major: equal quadrants are neighbours
+        TileCoord tc = locate_pos<256, 256>(g, n_big + xcd_remap(t, n_rest));
+        const GemmDesc& P = g.p[tc.p];
+        tc.m0 += (quad >> 1) * 128;
+        tc.n0 += (quad & 1) * 128;
+        if (tc.m0 >= P.m || tc.n0 >= P.n) return;
+        const T* A = reinterpret_cast<const T*>(P.a) + (int64_t)tc.batch * P.stride_a;
+        const T* B = reinterpret_cast<const T*>(P.b) + (int64_t)tc.batch * P.stride_b;
+        T* C = reinterpret_cast<T*>(P.c) + (int64_t)tc.batch * P.stride_c;
+        Engine<T, 128, 128, 64, 2, 2, 4> e;
+        e.init(smem_raw);
+        e.set_tile(P, A, B, tc.m0, tc.n0);
+        e.zero_acc();
+        e.mac(0, P.k / 64);
+        e.store_tile(P, C, tc.m0, tc.n0);
+    }
+}
 
 // ---- one output tile per workgroup ------------------------------------------------------------------
 template <typename T, int BM, int BN, int BK, int NS, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void aid_gemm_nt_pipe_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const TileCoord tc = locate_tile<BM, BN>(g);
+    const TileCoord tc = locate_tile<BM, BN>(g, blockIdx.x, gridDim.x);
     const GemmDesc& P = g.p[tc.p];
     const T* A = reinterpret_cast<const T*>(P.a) + (int64_t)tc.batch * P.stride_a;
     const T* B = reinterpret_cast<const T*>(P.b) + (int64_t)tc.batch * P.stride_b;
@@ -433,101 +616,6 @@ __global__ __launch_bounds__(WM * WN * 64) void aid_gemm_nt_pipe_kernel(const Ge
     e.zero_acc();
     e.mac(0, P.k / BK);
     e.store_tile(P, C, tc.m0, tc.n0);
-}
-
-// ---- stream-K: a persistent grid (one workgroup per CU) splits the (tile, K-tile) iteration space of the whole
-// group evenly, so a launch whose tile count is not a multiple of the CU count (e.g. 560 tiles on 256 CUs)
-// has no ragged tail.  A workgroup's range is contiguous: [tail of a tile][whole tiles][head of a tile].
-//   * a segment that does not start at k = 0 (only ever the FIRST segment of a workgroup) is a contribution:
-//     the fp32 partial tile goes to this workgroup's scratch slot, then its flag is published (agent-scope
-//     release);
-//   * a segment that starts at k = 0 but stops early makes this workgroup the tile's owner: it waits for the
-//     flags of the following workgroup(s) — which computed their contribution FIRST, long before — adds the
-//     partials and stores the tile.
-// Contributors never wait, dependencies only point to higher workgroup ids: no cycle, no residency assumption
-// beyond forward progress.  Every spin is bounded (timeout -> *err = 1, result wrong but no hang).
-struct SkArgs {
-    GemmGroup g;
-    int32_t  iter_start[AID_GEMM_MAX_PROBLEMS + 1];   // prefix sums of tiles * k-tiles per problem
-    int32_t  nk[AID_GEMM_MAX_PROBLEMS];
-    int32_t* flags;                                   // [gridDim.x], zeroed by a memset node before every launch
-    float*   partials;                                // [gridDim.x][BM * BN]
-    int32_t* err;
-};
-
-template <typename T, int BM, int BN, int BK, int NS, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void aid_gemm_nt_sk_kernel(const SkArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    typedef Engine<T, BM, BN, BK, NS, WM, WN> E;
-    E e;
-    e.init(smem_raw);
-    const int G = gridDim.x;
-    const int lid = xcd_remap(blockIdx.x, G);          // neighbours in the iteration space share an XCD
-    const int64_t total = a.iter_start[a.g.n_problems];
-    const int it_begin = (int)(total * lid / G), it_end = (int)(total * (lid + 1) / G);
-    int* s_ok = reinterpret_cast<int*>(smem_raw + E::SMEM);   // in the dynamic segment: a second __shared__ object
-                                                              // would make hipcc drain vmcnt before every ds_read
-
-    for (int it = it_begin; it < it_end;) {
-        int p = 0;
-#pragma unroll
-        for (int i = 1; i < AID_GEMM_MAX_PROBLEMS; ++i)
-            if (i < a.g.n_problems && it >= a.iter_start[i]) p = i;
-        const GemmDesc& P = a.g.p[p];
-        const int nk = a.nk[p];
-        const int rel = it - a.iter_start[p];
-        int tile = rel / nk;
-        const int k0 = rel - tile * nk;
-        const int k1 = min(nk, k0 + (it_end - it));
-        const int tiles_n = (P.n + BN - 1) / BN, tiles_m = (P.m + BM - 1) / BM;
-        const int batch = tile / (tiles_m * tiles_n);
-        tile -= batch * tiles_m * tiles_n;
-        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-        const T* A = reinterpret_cast<const T*>(P.a) + (int64_t)batch * P.stride_a;
-        const T* B = reinterpret_cast<const T*>(P.b) + (int64_t)batch * P.stride_b;
-        T* C = reinterpret_cast<T*>(P.c) + (int64_t)batch * P.stride_c;
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores of the previous segment: the ring counts DMAs only
-        __syncthreads();
-        e.set_tile(P, A, B, m0, n0);
-        e.zero_acc();
-        e.mac(k0, k1);
-        it += k1 - k0;
-
-        if (k0 > 0) {                                       // contribution to a tile another workgroup owns
-            e.write_partial(a.partials + (size_t)lid * (BM * BN));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (e.tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(a.flags + lid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            continue;
-        }
-        if (k1 < nk) {                                      // owner: collect the rest of the K range from the successors
-            int remaining = nk - k1;
-            for (int c = lid + 1; remaining > 0 && c < G; ++c) {
-                const int c_iters = (int)(total * (c + 1) / G) - (int)(total * c / G);
-                if (c_iters == 0) continue;
-                if (e.tid == 0) {
-                    int ok = 1;
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(a.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 24)) { ok = 0; *a.err = 1; break; }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    *s_ok = ok;
-                }
-                __syncthreads();
-                if (*s_ok) e.add_partial(a.partials + (size_t)c * (BM * BN));
-                __syncthreads();
-                remaining -= min(remaining, c_iters);
-            }
-        }
-        e.store_tile(P, C, m0, n0);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,111 +650,94 @@ static hipError_t launch_pipe(GemmGroup& g, hipStream_t stream) {
                             &attr_set, g, plan_tiles(g, BM, BN), stream, WM * WN * 64);
 }
 
-// persistent scratch of the stream-K path (flags + fp32 partial tiles), one per device, allocated on first use
-// (do the first call outside stream capture); calls on different streams of one device must not overlap
-struct SkScratch {
-    int32_t* flags = nullptr;
-    float*   partials = nullptr;
-    int32_t* err = nullptr;
-    int      grid = 0;
-    size_t   tile_elems = 0;
-};
-static SkScratch g_sk[16];
-
-static hipError_t sk_scratch(int grid, size_t tile_elems, SkScratch** out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    SkScratch& s = g_sk[dev & 15];
-    if (s.grid < grid || s.tile_elems < tile_elems) {
-        if (s.flags) { (void)hipFree(s.flags); (void)hipFree(s.partials); }
-        s.grid = grid > s.grid ? grid : s.grid;
-        s.tile_elems = tile_elems > s.tile_elems ? tile_elems : s.tile_elems;
-        e = hipMalloc(&s.flags, (size_t)(s.grid + 16) * sizeof(int32_t));
-        if (e != hipSuccess) return e;
-        e = hipMalloc(&s.partials, (size_t)s.grid * s.tile_elems * sizeof(float));
-        if (e != hipSuccess) return e;
-        e = hipMemset(s.flags, 0, (size_t)(s.grid + 16) * sizeof(int32_t));
-        if (e != hipSuccess) return e;
-        s.err = s.flags + s.grid;
-    }
-    *out = &s;
-    return hipSuccess;
-}
-
 static int g_num_cu = 0;
 
-template <typename T, int BM, int BN, int BK, int NS, int WM, int WN>
-static hipError_t launch_sk(GemmGroup& g, hipStream_t stream) {
-    typedef Engine<T, BM, BN, BK, NS, WM, WN> E;
-    static bool attr_set = false;
-    SkArgs a;
-    plan_tiles(g, BM, BN);
-    a.g = g;
-    int iters = 0;
-    for (int i = 0; i < g.n_problems; ++i) {
-        a.iter_start[i] = iters;
-        a.nk[i] = g.p[i].k / BK;
-        iters += (g.tile_start[i + 1] - g.tile_start[i]) * a.nk[i];
-    }
-    for (int i = g.n_problems; i <= AID_GEMM_MAX_PROBLEMS; ++i) a.iter_start[i] = iters;
-    for (int i = g.n_problems; i < AID_GEMM_MAX_PROBLEMS; ++i) a.nk[i] = 1;
-    if (iters <= 0) return hipSuccess;
+static int num_cu() {
     if (g_num_cu == 0) {
         int dev = 0;
         hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return hipErrorInvalidDevice;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
         g_num_cu = pr.multiProcessorCount;
     }
-    const int grid = iters < g_num_cu ? iters : g_num_cu;
-    SkScratch* sc = nullptr;
-    hipError_t e = sk_scratch(g_num_cu, (size_t)BM * BN, &sc);
-    if (e != hipSuccess) return e;
-    a.flags = sc->flags;
-    a.partials = sc->partials;
-    a.err = sc->err;
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(aid_gemm_nt_sk_kernel<T, BM, BN, BK, NS, WM, WN>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)E::SMEM + 16);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    return g_num_cu;
+}
+
+// Plan of the ping-pong path: n_big 256 x 256 tiles (whole CU rounds) + the ragged rest as 128 x 128 tiles.
+struct PpPlan {
+    int tiles, n_big, n_small;
+    double rounds;                          // cost in units of one big-tile round
+};
+static PpPlan plan_pp(GemmGroup& g, int ncu, int nk) {
+    PpPlan pl;
+    pl.tiles = plan_tiles(g, 256, 256);
+    int full = pl.tiles / ncu, rest = pl.tiles % ncu;
+    pl.n_big = pl.tiles;
+    pl.n_small = 0;
+    pl.rounds = full + (rest ? 1 : 0);
+    if (full > 0 && rest > 0 && rest <= ncu / 2 && ncu % 8 == 0) {   // a last round at <= 50 % occupancy: cut it up
+        pl.n_big = full * ncu;
+        pl.n_small = 4 * rest;
+        pl.rounds = full + ((4 * rest + ncu - 1) / ncu) * (2.0 + 0.6 * nk) / (6.0 + 1.62 * nk);
     }
-    e = hipMemsetAsync(sc->flags, 0, (size_t)grid * sizeof(int32_t), stream);      // flags are per-launch state
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((aid_gemm_nt_sk_kernel<T, BM, BN, BK, NS, WM, WN>), dim3(grid), dim3(WM * WN * 64), E::SMEM + 16, stream, a);
-    return hipGetLastError();
+    return pl;
 }
 
 template <typename T>
-static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream) {
-    bool k64 = true;
-    for (int i = 0; i < g.n_problems; ++i) k64 = k64 && (g.p[i].k % 64 == 0);
-    // development knob (tools/kbench.py): AID_GEMM_VARIANT selects the tile configuration; default 7
-    // (table: profiles/r01_gemm_variants.txt)
-    static const int variant = getenv("AID_GEMM_VARIANT") ? atoi(getenv("AID_GEMM_VARIANT")) : 7;
-    if (k64) {
-        switch (variant) {
-            case 1:  return launch_pipe<T, 128, 128, 64, 2, 2, 2>(g, stream);   // 4 waves, 64x64 wave tiles, 2 WG/CU
-            case 10: return launch_pipe<T, 256, 128, 64, 2, 4, 2>(g, stream);   // 8 waves, 64x64 wave tiles, 96 KB
-            case 11: return launch_pipe<T, 256, 128, 64, 3, 4, 2>(g, stream);   // same, 3 stages (144 KB)
-            case 12: return launch_pipe<T, 256, 256, 64, 2, 2, 4>(g, stream);   // 8 waves, 128x64 wave tiles, 128 KB
-            case 13: return launch_pipe<T, 256, 128, 32, 4, 4, 2>(g, stream);   // BK 32, 4 stages (96 KB)
-            case 14: return launch_pipe<T, 256, 128, 32, 6, 4, 2>(g, stream);   // BK 32, 6 stages (144 KB)
-            case 15: return launch_pipe<T, 128, 128, 64, 2, 1, 2>(g, stream);   // 2 waves, 128x64 wave tiles, 2 WG/CU
-            case 16: return launch_pipe<T, 256, 128, 64, 2, 2, 2>(g, stream);   // 4 waves, 128x64 wave tiles, 1 WG/CU
-            case 17: return launch_pipe<T, 128, 128, 64, 2, 2, 1>(g, stream);   // 2 waves, 64x128 wave tiles
-            case 20: return launch_sk<T, 256, 128, 64, 3, 4, 2>(g, stream);     // stream-K, 256x128 tiles
-            case 21: return launch_sk<T, 256, 256, 64, 2, 2, 4>(g, stream);     // stream-K, 256x256 tiles
-            case 22: return launch_sk<T, 128, 128, 64, 2, 2, 4>(g, stream);     // stream-K, 128x128 tiles (1 WG/CU)
-            default: return launch_pipe<T, 128, 128, 64, 2, 2, 4>(g, stream);   // 7: 8 waves, 64x32 wave tiles, 2 WG/CU
-        }
+static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl) {
+    static bool attr_set = false;
+    if (pl.tiles <= 0) return hipSuccess;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(aid_gemm_nt_pp_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PingPong<T>::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
     }
-    static bool s0 = false;
-    return launch_with_smem(aid_gemm_nt_kernel<T>, (size_t)2 * (GBM + GBN) * GLD * sizeof(T), &s0, g,
-                            plan_tiles(g, GBM, GBN), stream, GTHREADS);
+    hipLaunchKernelGGL(aid_gemm_nt_pp_kernel<T>, dim3(pl.n_big + pl.n_small), dim3(512), PingPong<T>::SMEM, stream, g,
+                       pl.n_big);
+    return hipGetLastError();
 }
 
-hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream) {
+// Two engines serve the k % 64 == 0 shapes; which one a launch gets is decided by a two-line cost model fitted to
+// the ten projection launches of the SD1.5 / SDXL stacks (tools/kbench_proj.py, profiles/r01_gemm_variants.txt; it
+// picks the measured winner on all ten):
+//   lock-step 128 x 128 (2 workgroups / CU):  3 + ceil_half(tiles128 / (2 CUs)) * (4.1 + 1.09 nk)   us
+//   ping-pong 256 x 256 (1 workgroup / CU):   5 + rounds * (6 + 1.62 nk)                            us
+// The big tiles win on long K loops and many tiles (SDXL C = 1280: 170 -> 145 us, 69 -> 58 us); the small ones on
+// short K loops (SD1.5 C = 320), on launches of less than half a round, and whenever the K loops of a group differ
+// (the text-context projections of cross-attention: their tiles are mostly padding at 256 x 256).
+template <typename T>
+static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** variant) {
+    bool k64 = true;
+    for (int i = 0; i < g.n_problems; ++i) k64 = k64 && (g.p[i].k % 64 == 0);
+    if (!k64) {
+        static bool s0 = false;
+        if (variant) *variant = "edge";
+        return launch_with_smem(aid_gemm_nt_kernel<T>, (size_t)2 * (GBM + GBN) * GLD * sizeof(T), &s0, g,
+                                plan_tiles(g, GBM, GBN), stream, GTHREADS);
+    }
+    // development knob (tools/gemm_shapes.py): AID_GEMM_VARIANT=7 / 31 forces the lock-step / ping-pong engine
+    static const int force = getenv("AID_GEMM_VARIANT") ? atoi(getenv("AID_GEMM_VARIANT")) : 0;
+    const int ncu = num_cu();
+    if (ncu <= 0) return hipErrorInvalidDevice;
+    bool pp = false;
+    PpPlan pl = {};
+    if (!g.interleave && g.n_problems > 0) {
+        const int nk = g.p[0].k / 64;
+        pl = plan_pp(g, ncu, nk);
+        const int t128 = plan_tiles(g, 128, 128);
+        const double r128 = 0.5 * (double)((2 * t128 + 2 * ncu - 1) / (2 * ncu));       // rounds of 2 CUs-fulls, in halves
+        const double cost_ls = 3.0 + r128 * (4.1 + 1.09 * nk);
+        const double cost_pp = 5.0 + pl.rounds * (6.0 + 1.62 * nk);
+        pp = cost_pp < 0.95 * cost_ls;
+        if (force == 31) pp = true;
+    }
+    if (force == 7) pp = false;
+    if (variant) *variant = !pp ? "lockstep128" : pl.n_small ? "pingpong256+tail128" : "pingpong256";
+    if (pp) return launch_pp<T>(g, stream, pl);
+    return launch_pipe<T, 128, 128, 64, 2, 2, 4>(g, stream);       // 8 waves, 64 x 32 wave tiles, 2 workgroups / CU
+}
+
+hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const char** variant) {
     // Longest K loop first: blocks are dispatched in grid order, so the tiles that take longest (the K = 2048
     // text-context projections of a cross-attention layer next to its K = 1280 query projection) start first
     // and finish under the rest instead of forming the tail of the launch (measured: 107 -> 7x us).
@@ -679,7 +750,7 @@ hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream) {
             g.p[j] = g.p[j - 1];
             g.p[j - 1] = t;
         }
-    return dtype == AID_DTYPE_F16 ? launch_gemm<f16>(g, stream) : launch_gemm<bf16>(g, stream);
+    return dtype == AID_DTYPE_F16 ? launch_gemm<f16>(g, stream, variant) : launch_gemm<bf16>(g, stream, variant);
 }
 
 }  // namespace aid

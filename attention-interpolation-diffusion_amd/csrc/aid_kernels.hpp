@@ -26,7 +26,7 @@ struct GemmGroup {                        // passed by value as the kernel argum
 };
 
 // picks the tile shape, fills g.tile_start and launches
-hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream);
+hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const char** variant = nullptr);
 
 // attention core; returns hipSuccess / error, writes the variant name for profiling
 hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** variant);

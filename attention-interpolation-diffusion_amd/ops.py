@@ -173,6 +173,10 @@ def last_attn_variant() -> str:
     return _lib.load().aid_last_attn_variant().decode()
 
 
+def last_gemm_variant() -> str:
+    return _lib.load().aid_last_gemm_variant().decode()
+
+
 def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor, wk: torch.Tensor,
                   wv: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], heads: int, *,
                   mode: str = "plain", fused: bool = False, coef: Optional[torch.Tensor] = None,

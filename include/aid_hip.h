@@ -197,6 +197,8 @@ int         aid_abi_version(void);
 const char* aid_strerror(int code);
 /* name of the kernel variant the last aid_attn_fwd call on this thread launched (for profiling) */
 const char* aid_last_attn_variant(void);
+/* same for the last aid_gemm_nt launch: "lockstep128", "pingpong256" (+ "+tail128") or "edge" */
+const char* aid_last_gemm_variant(void);
 /* device properties of the current device: returns AID_OK and fills what is non-NULL */
 int aid_device_info(int* n_cu, int* clock_khz, char* arch /* >= 32 bytes */);
 

@@ -47,6 +47,33 @@ def test_gemm_nt_vs_fp64(dtype, mnk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("mnk,engine", [((33000, 512, 640), "pingpong256+tail128"),     # 258 big tiles: 256 + 2 cut in four
+                                        ((33001, 504, 640), "pingpong256+tail128"),     # ragged m and n edges
+                                        ((14336, 1280, 1280), "pingpong256+tail128"),   # SDXL out projection
+                                        ((3584, 3840, 1280), "pingpong256"),            # 210 tiles: one partial round
+                                        ((57344, 320, 320), "lockstep128"),             # short K loop
+                                        ((1000, 1280, 2048), "lockstep128")])           # too few tiles
+def test_gemm_engine_selection_and_parity(dtype, mnk, engine):
+    """Both k % 64 == 0 engines against fp64 on sampled rows (every row panel edge included), and the cost model
+    sends each shape to the engine the stack measurements favour (profiles/r01_gemm_variants.txt)."""
+    m, n, k = mnk
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(dtype)
+    b = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype)
+    bias = torch.randn(n, generator=g).to(dtype)
+    y = ops.linear(a.to(DEV), b.to(DEV), bias.to(DEV))
+    assert ops.last_gemm_variant() == engine
+    rows = torch.unique(torch.cat([torch.arange(0, m, 997), torch.arange(255, m, 256), torch.arange(256, m, 256),
+                                   torch.tensor([m - 1])]))
+    ref = to_np64(a[rows]) @ to_np64(b).T + to_np64(bias)
+    assert rel_l2(to_np64(y[rows.to(DEV)]), ref) < TOL_GEMM[dtype]
+    # every output element was written exactly once with a finite value of the right magnitude
+    assert torch.isfinite(y).all()
+    col = (y.float() - bias.to(DEV).float()).square().mean(dim=0).sqrt().cpu()      # a b^T has unit variance
+    assert (col > 0.8).all() and (col < 1.25).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
 @pytest.mark.parametrize("shape", [(3, 77, 96, 80), (7, 200, 64, 128), (2, 5, 8, 40)])
 def test_kv_projection_writes_transposed_values_and_zero_padding(dtype, shape):
     f, l, cc, c = shape
