@@ -305,7 +305,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     memset(&at, 0, sizeof(at));
     at.q = q; at.k = k; at.vt = vt; at.out = o;
     if (a.mode == AID_MODE_INNER) {
-        if (a.ctx_map) return AID_ERR_ARG;      // the lerped rows are per frame; shared-context maps are for PLAIN / OUTER
+        // begin / end are rows of k / vt (context rows when ctx_map is given); the interpolated rows are per FRAME
         at.k2 = ws + cv.k2; at.vt2 = ws + cv.vt2;
         const int interior = a.n_frames - a.n_plain - 2;
         rc = lerp_kv_impl(k, vt, ws + cv.k2, ws + cv.vt2, a.coef, a.n_frames, a.begin, a.end, (int64_t)l * a.c,

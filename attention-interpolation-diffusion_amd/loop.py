@@ -18,7 +18,7 @@ unconditional plain) are captured once into hipGraphs and replayed per step, so 
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional
+from typing import Callable, Dict, Optional, Sequence
 
 import torch
 
@@ -61,6 +61,18 @@ def set_aid_active(unet, active: bool, plain_tail: int = 0) -> None:
             proc.plain_tail = int(plain_tail)
 
 
+def set_ctx_index(unet, ctx_index: Optional[Sequence[int]]) -> None:
+    """Tell every processor which row of ``encoder_hidden_states`` each frame of the next UNet call uses
+    (None = one context per frame).  See InterpolatedAttnProcessor.ctx_index."""
+    idx = None if ctx_index is None else [int(i) for i in ctx_index]
+    for proc in unet.attn_processors.values():
+        if hasattr(proc, "ctx_index"):
+            proc.ctx_index = idx
+        inner = getattr(proc, "original_attn", None)
+        if inner is not None and hasattr(inner, "ctx_index"):
+            inner.ctx_index = idx
+
+
 class AidDenoiseLoop:
     """Replays the per-step attention work of an interpolation run.
 
@@ -70,18 +82,29 @@ class AidDenoiseLoop:
 
     def __init__(self, unet, sample, cond, uncond, num_inference_steps: int = 50, warmup_ratio: float = 0.5,
                  guidance_scale: float = 7.5, use_graphs: bool = True, combine: Optional[Callable] = None,
-                 batched_cfg: bool = False):
+                 batched_cfg: bool = False, ctx_index: Optional[Sequence[int]] = None):
         """``batched_cfg``: run the conditional and the unconditional pass of a step as ONE UNet call over the
         batch [cond frames ; uncond frames] (how stock diffusers pipelines do classifier-free guidance).  The
         AID processors treat the second half as plain riders (negative coefficients), so the result equals the
         reference's two separate calls while every GEMM sees twice the rows and the launch count halves."""
+        """``ctx_index`` (frame -> row of ``cond`` / ``uncond``): the sequence shares text contexts (PAID guide
+        prompt, sequence.py); ``cond`` / ``uncond`` then hold the DISTINCT contexts only."""
         self.unet, self.sample, self.cond, self.uncond = unet, sample, cond, uncond
         self.batched_cfg = batched_cfg
+        first = next(iter(sample.values())) if isinstance(sample, dict) else sample
+        self.n_frames = first.shape[0]
+        self.ctx_index = None if ctx_index is None else [int(i) for i in ctx_index]
+        if self.ctx_index is not None and len(self.ctx_index) != self.n_frames:
+            raise ValueError("ctx_index needs one entry per frame")
+        if self.ctx_index is None and cond.shape[0] != self.n_frames:
+            raise ValueError("one context per frame expected (or pass ctx_index)")
+        self.ctx_index2 = None
         if batched_cfg:
             dup = (lambda t: torch.cat([t, t], dim=0))
             self.sample2 = {k: dup(v) for k, v in sample.items()} if isinstance(sample, dict) else dup(sample)
             self.ctx2 = torch.cat([cond, uncond], dim=0)
-            self.n_frames = cond.shape[0]
+            if self.ctx_index is not None:
+                self.ctx_index2 = self.ctx_index + [i + cond.shape[0] for i in self.ctx_index]
         self.num_inference_steps = num_inference_steps
         self.warmup_steps = int(num_inference_steps * warmup_ratio)        # pipeline_interpolated_sd.py:1831
         self.guidance_scale = guidance_scale
@@ -97,6 +120,7 @@ class AidDenoiseLoop:
 
     # -- the three distinct passes ---------------------------------------------------------------
     def _pass(self, which: str):
+        set_ctx_index(self.unet, self.ctx_index2 if which.startswith("both") else self.ctx_index)
         if which == "both_aid":
             set_aid_active(self.unet, True, plain_tail=self.n_frames)
             return self.unet(self.sample2, self.ctx2)

@@ -14,11 +14,14 @@ CPU tensors, fp32 tensors or a missing library raise.
 Differences from the reference that are deliberate and documented:
   * de-activated processors with ``original_attn=None`` run plain attention on the same HIP
     kernel (the reference requires a wrapped diffusers processor);
-  * the per-call host->device copy of ``coef`` (interpolation.py:663) is cached on the device.
+  * the per-call host->device copy of ``coef`` (interpolation.py:663) is cached on the device;
+  * optional ``ctx_index`` (attribute or keyword of ``__call__``, e.g. through ``cross_attention_kwargs``): frames
+    that share a text context (PAID guide prompt) have its keys / values projected once.  Results are bit-identical
+    to passing the repeated contexts.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 from torch import nn
@@ -47,7 +50,12 @@ class InterpolatedAttnProcessor(nn.Module):
         # build-specific: number of extra frames appended AFTER the `size` interpolated frames that run plain
         # attention in the same call (the unconditional half of a batched classifier-free-guidance step)
         self.plain_tail = 0
+        # build-specific: frame -> row of ``encoder_hidden_states`` when several frames share one text context
+        # (PAID guide prompt: [start, guide x (N-2), end] = 3 distinct contexts, sequence.py).  The keys / values of
+        # a shared context are then projected once instead of once per frame.  None = one context per frame.
+        self.ctx_index: Optional[Sequence[int]] = None
         self._coef_cache: Dict[Tuple, torch.Tensor] = {}
+        self._ctx_cache: Dict[Tuple, Tuple] = {}
 
     def deactivate(self):
         self.activated = False
@@ -82,6 +90,30 @@ class InterpolatedAttnProcessor(nn.Module):
             hit = hit.to(device).contiguous()
             self._coef_cache[key] = hit
         return hit
+
+
+def _shared_context(cache: Dict, ctx_index, ctx: torch.Tensor, batch: int):
+    """(distinct contexts [n_distinct, L, Cc], device int32 map [batch], host list) for a frame -> context map."""
+    idx = [int(i) for i in (ctx_index.tolist() if torch.is_tensor(ctx_index) else ctx_index)]
+    if len(idx) != batch:
+        raise RuntimeError(f"ctx_index has {len(idx)} entries for a batch of {batch} frames")
+    n_distinct = max(idx) + 1
+    if min(idx) < 0 or sorted(set(idx)) != list(range(n_distinct)):
+        raise RuntimeError("ctx_index must use every context row 0 .. n_distinct-1")
+    key = (tuple(idx), ctx.device)
+    hit = cache.get(key)
+    if hit is None:
+        cache.clear()
+        first = [idx.index(r) for r in range(n_distinct)]
+        hit = (torch.tensor(idx, dtype=torch.int32, device=ctx.device),
+               torch.tensor(first, dtype=torch.long, device=ctx.device))
+        cache[key] = hit
+    dev_map, first = hit
+    if ctx.shape[0] == batch and n_distinct != batch:
+        ctx = ctx.index_select(0, first)          # caller passed one (repeated) context per frame
+    elif ctx.shape[0] != n_distinct:
+        raise RuntimeError(f"encoder_hidden_states has {ctx.shape[0]} rows; ctx_index needs {n_distinct} (or {batch})")
+    return ctx.contiguous(), dev_map, idx
 
 
 # ---------------------------------------------------------------------------------------------
@@ -126,18 +158,25 @@ def _weights(attn):
 
 
 def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidden_states,
-              attention_mask, temb, mode: str):
+              attention_mask, temb, mode: str, ctx_index=None):
     residual, x, ctx, shape4 = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
     wq, wk, wv, wo, bo = _weights(attn)
     coef = None
     if mode != "plain":
         coef = proc._coef_device(x.device, x.dtype, x.shape[0])
-    if ctx is not None:
-        ctx = ctx.contiguous()
     n_aid = proc.coef.numel()
+    begin, end = 0, (n_aid - 1) if mode != "plain" else -1
+    ctx_map = None
+    ctx_index = proc.ctx_index if ctx_index is None else ctx_index
+    if ctx is not None and ctx_index is not None:
+        ctx, ctx_map, idx = _shared_context(proc._ctx_cache, ctx_index, ctx, x.shape[0])
+        if mode != "plain":
+            begin, end = idx[0], idx[n_aid - 1]       # end-point rows of the key / value tensors
+    elif ctx is not None:
+        ctx = ctx.contiguous()
     y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode,
                           fused=proc.is_fused if mode != "plain" else False, coef=coef,
-                          begin=0, end=(n_aid - 1) if mode != "plain" else -1,
+                          begin=begin, end=end, ctx_map=ctx_map,
                           n_plain=proc.plain_tail if mode != "plain" else 0)
     return _epilogue(attn, y, residual, shape4)
 
@@ -147,13 +186,21 @@ class HipAttnProcessor:
     ``original_attn`` this package installs so the de-activated passes of the denoising loop
     (every unconditional pass and every post-warm-up step) stay on one code path."""
 
+    def __init__(self):
+        self.ctx_index: Optional[Sequence[int]] = None      # see InterpolatedAttnProcessor.ctx_index
+        self._ctx_cache: Dict[Tuple, Tuple] = {}
+
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                 *args, **kwargs):
+                 *args, ctx_index=None, **kwargs):
         residual, x, ctx, shape4 = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         wq, wk, wv, wo, bo = _weights(attn)
-        if ctx is not None:
+        ctx_map = None
+        ctx_index = self.ctx_index if ctx_index is None else ctx_index
+        if ctx is not None and ctx_index is not None:
+            ctx, ctx_map, _ = _shared_context(self._ctx_cache, ctx_index, ctx, x.shape[0])
+        elif ctx is not None:
             ctx = ctx.contiguous()
-        y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain")
+        y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map)
         return _epilogue(attn, y, residual, shape4)
 
 
@@ -167,12 +214,17 @@ class OuterInterpolatedAttnProcessor(InterpolatedAttnProcessor):
         super().__init__(t=t, size=size, is_fused=is_fused, alpha=alpha, beta=beta)
         self.original_attn = original_attn
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 ctx_index=None):
+        ctx_index = self.ctx_index if ctx_index is None else ctx_index
         if not self.activated:
             if self.original_attn is not None:
+                if ctx_index is not None:           # only a processor that knows the keyword can take the map
+                    return self.original_attn(attn, hidden_states, encoder_hidden_states, attention_mask, temb,
+                                              ctx_index=ctx_index)
                 return self.original_attn(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
-            return _run_text(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, "plain")
-        return _run_text(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, "outer")
+            return _run_text(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, "plain", ctx_index)
+        return _run_text(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, "outer", ctx_index)
 
 
 class InnerInterpolatedAttnProcessor(InterpolatedAttnProcessor):
@@ -184,12 +236,17 @@ class InnerInterpolatedAttnProcessor(InterpolatedAttnProcessor):
         super().__init__(t=t, size=size, is_fused=is_fused, alpha=alpha, beta=beta)
         self.original_attn = original_attn
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 ctx_index=None):
+        ctx_index = self.ctx_index if ctx_index is None else ctx_index
         if not self.activated:
             if self.original_attn is not None:
+                if ctx_index is not None:           # only a processor that knows the keyword can take the map
+                    return self.original_attn(attn, hidden_states, encoder_hidden_states, attention_mask, temb,
+                                              ctx_index=ctx_index)
                 return self.original_attn(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
-            return _run_text(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, "plain")
-        return _run_text(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, "inner")
+            return _run_text(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, "plain", ctx_index)
+        return _run_text(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, "inner", ctx_index)
 
 
 # ---------------------------------------------------------------------------------------------

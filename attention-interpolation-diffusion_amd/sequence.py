@@ -34,6 +34,14 @@ class SequenceBatch:
     n_distinct_ctx: int
 
 
+def distinct_contexts(batch: "SequenceBatch"):
+    """(cond [n_distinct, L, Cc], uncond [n_distinct, L, Cc], ctx_index list) — what AidDenoiseLoop(ctx_index=...)
+    and the processors' ``ctx_index`` take: each distinct text context once, in order of first use."""
+    idx = [int(i) for i in batch.ctx_index.tolist()]
+    first = torch.tensor([idx.index(r) for r in range(batch.n_distinct_ctx)], dtype=torch.long)
+    return batch.cond.index_select(0, first), batch.uncond.index_select(0, first), idx
+
+
 def _ctx_index(n: int, guided: bool) -> torch.Tensor:
     if guided:                       # [start, guide x (n-2), end] -> 3 distinct contexts
         idx = [0] + [1] * (n - 2) + [2]

@@ -55,19 +55,24 @@ def parse():
     ap.add_argument("--separate-passes", action="store_true",
                     help="run the cond and the uncond pass as two UNet calls like the reference loop "
                          "(default: one call over [cond ; uncond], same work, same results)")
+    ap.add_argument("--guide-prompt", default="auto", choices=["auto", "on", "off"],
+                    help="PAID: interior frames share the guide prompt's text context (3 distinct contexts); "
+                         "auto = on for sdxl (BASELINE configs[2]), off for sd15 (configs[1]: per-frame embeddings)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def make_inputs(unet, n_frames, dtype, device, seed=1002):
-    """Hidden state per resolution level ~ N(0,1) (post-LayerNorm scale) and text contexts ~ N(0,1)."""
+def make_inputs(unet, n_frames, dtype, device, seed=1002, n_ctx=None):
+    """Hidden state per resolution level ~ N(0,1) (post-LayerNorm scale) and ``n_ctx`` text contexts ~ N(0,1)
+    (one per frame, or the 3 distinct ones [start, guide, end] of a PAID run)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
+    n_ctx = n_frames if n_ctx is None else n_ctx
     xs = {}
     for (s, c) in unet.level_shapes():
         xs[(s, c)] = torch.randn(n_frames, s, c, generator=g).to(dtype).to(device)
-    cond = torch.randn(n_frames, unet.text_len, unet.cross_dim, generator=g).to(dtype).to(device)
-    uncond = torch.randn(n_frames, unet.text_len, unet.cross_dim, generator=g).to(dtype).to(device)
+    cond = torch.randn(n_ctx, unet.text_len, unet.cross_dim, generator=g).to(dtype).to(device)
+    uncond = torch.randn(n_ctx, unet.text_len, unet.cross_dim, generator=g).to(dtype).to(device)
     return xs, cond, uncond
 
 
@@ -184,18 +189,25 @@ def main():
     unet = aid_amd.AttnStackUNet(model, dtype=dtype, device=device)
     coef = aid_amd.generate_beta_tensor(n_total, steps, steps)
     coef[0], coef[-1] = 0, 1
-    xs, cond, uncond = make_inputs(unet, n_total, dtype, device)
+    guided = args.guide_prompt == "on" or (args.guide_prompt == "auto" and model == "sdxl")
+    # PAID (gradio ...stable_diffusion.py:221-229): contexts [start, guide x (N-2), end] -> 3 distinct rows
+    global_ctx = ([0] + [1] * (n_total - 2) + [2]) if guided else list(range(n_total))
+    xs, cond, uncond = make_inputs(unet, n_total, dtype, device, n_ctx=3 if guided else None)
     if world > 1:                            # conditioning comes from rank 0 (north_star: RCCL broadcast)
         named = {f"x{s}_{c}": t for (s, c), t in xs.items()}
         named.update(cond=cond, uncond=uncond)
         adist.broadcast_conditioning(named, src=0)
     xs = {k: adist.shard_rows(v, shard) for k, v in xs.items()}
-    cond, uncond = adist.shard_rows(cond, shard), adist.shard_rows(uncond, shard)
+    rows = [global_ctx[f] for f in shard.index]              # context row of every local frame ...
+    used = sorted(set(rows), key=rows.index)                 # ... renumbered in order of first local use
+    ctx_index = [used.index(r) for r in rows] if guided else None
+    sel = torch.tensor(used, device=device)
+    cond, uncond = cond.index_select(0, sel).contiguous(), uncond.index_select(0, sel).contiguous()
     local_coef = coef[list(shard.index)]
     install_sequence_processors(unet, shard.n_local, early=early, num_inference_steps=steps, coef=local_coef)
 
     loop = AidDenoiseLoop(unet, xs, cond, uncond, num_inference_steps=steps, warmup_ratio=args.warmup_ratio,
-                          use_graphs=not args.no_graph, batched_cfg=not args.separate_passes)
+                          use_graphs=not args.no_graph, batched_cfg=not args.separate_passes, ctx_index=ctx_index)
     gather_key = unet.level_shapes()[-1]
 
     def run_steps(idx):
@@ -241,6 +253,8 @@ def main():
             "aid_steps": loop.warmup_steps,
             "passes_per_step": ("cond + uncond (CFG), two UNet calls" if args.separate_passes
                                 else "cond + uncond (CFG) batched in one UNet call [cond ; uncond]"),
+            "contexts": ("PAID guide prompt: interior frames share one text context (3 distinct per pass), keys/values "
+                         "projected once per distinct context" if guided else "one text context per frame"),
             "coef": f"BetaPPF(alpha=beta={steps})", "hipgraph": not args.no_graph,
             "parallelism": f"frame-shard x{world} (replicated end points, no per-layer collective)",
         },

@@ -11,6 +11,7 @@ from util import TOL, TOL_GEMM, make_attn, rel_l2, rounded, to_np64
 pytestmark = pytest.mark.gpu
 
 import aid_amd  # noqa: E402
+from aid_amd.loop import AidDenoiseLoop, install_sequence_processors
 from aid_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
@@ -370,6 +371,68 @@ def test_batched_cfg_equals_two_separate_calls(dtype, kind, cross):
     proc.plain_tail = 0
     with pytest.raises(RuntimeError, match="must match the size"):
         proc(attn, torch.cat([xc, xu]))
+
+
+# ------------------------------------------------------------------------------------------------
+# shared text contexts (PAID guide prompt): keys / values of a distinct context are projected once
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("kind,fused", [("outer", True), ("outer", False), ("inner", True), ("inner", False), ("plain", False)])
+def test_shared_contexts_equal_repeated_contexts(dtype, kind, fused):
+    n, s, heads, d, l, cc = 7, 150, 2, 64, 77, 96
+    c = heads * d
+    g = torch.Generator().manual_seed(33)
+    attn = aid_amd.AttnShim(c, heads, cc, dtype=dtype, device=DEV)
+    x = torch.randn(2 * n, s, c, generator=g).to(dtype).to(DEV)
+    distinct = torch.randn(6, l, cc, generator=g).to(dtype).to(DEV)       # cond: start, guide, end; uncond: same
+    idx = [0] + [1] * (n - 2) + [2]
+    idx2 = idx + [i + 3 for i in idx]
+    full = distinct[idx2].contiguous()                                     # what the reference loop would pass
+    if kind == "plain":
+        proc = aid_amd.HipAttnProcessor()
+        y_full = proc(attn, x, encoder_hidden_states=full)
+        y_kw = proc(attn, x, encoder_hidden_states=distinct, ctx_index=idx2)
+        proc.ctx_index = idx2
+        y_attr = proc(attn, x, encoder_hidden_states=full)                 # repeated rows are de-duplicated
+    else:
+        cls = aid_amd.OuterInterpolatedAttnProcessor if kind == "outer" else aid_amd.InnerInterpolatedAttnProcessor
+        proc = cls(size=n, is_fused=fused, alpha=3, beta=3)
+        proc.plain_tail = n                                                # batched CFG: uncond half rides along
+        y_full = proc(attn, x, encoder_hidden_states=full)
+        y_kw = proc(attn, x, encoder_hidden_states=distinct, ctx_index=idx2)
+        proc.ctx_index = idx2
+        y_attr = proc(attn, x, encoder_hidden_states=full)
+        # de-activated: the wrapped plain processor gets the map too
+        proc.deactivate()
+        proc.original_attn = aid_amd.HipAttnProcessor()
+        assert torch.equal(proc(attn, x, encoder_hidden_states=distinct), aid_amd.HipAttnProcessor()(attn, x, full))
+    assert torch.equal(y_kw, y_full) and torch.equal(y_attr, y_full)       # same kernels on the same rows: bitwise
+    with pytest.raises(RuntimeError, match="ctx_index"):
+        proc(attn, x, encoder_hidden_states=distinct, ctx_index=idx)       # wrong length
+    with pytest.raises(RuntimeError, match="rows"):
+        proc(attn, x, encoder_hidden_states=distinct[:5], ctx_index=idx2)  # too few context rows
+
+
+def test_loop_with_shared_contexts_matches_repeated_contexts():
+    n = 5
+    unet = aid_amd.AttnStackUNet("sdxl", dtype=torch.bfloat16, device=DEV, scale_down=16)
+    install_sequence_processors(unet, n, early="fused_outer", num_inference_steps=4)
+    g = torch.Generator().manual_seed(3)
+    xs = {(s, c): torch.randn(n, s, c, generator=g).to(torch.bfloat16).to(DEV) for (s, c) in unet.level_shapes()}
+    cond3 = torch.randn(3, unet.text_len, unet.cross_dim, generator=g).to(torch.bfloat16).to(DEV)
+    unc3 = torch.randn(3, unet.text_len, unet.cross_dim, generator=g).to(torch.bfloat16).to(DEV)
+    idx = [0, 1, 1, 1, 2]
+    outs = []
+    for shared in (True, False):
+        for batched in (True, False):
+            loop = AidDenoiseLoop(unet, xs, cond3 if shared else cond3[idx].contiguous(),
+                                  unc3 if shared else unc3[idx].contiguous(), num_inference_steps=4,
+                                  use_graphs=shared, batched_cfg=batched, ctx_index=idx if shared else None)
+            outs.append([loop.step(i) for i in (0, 3)])
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            for k in a:
+                assert torch.equal(a[k], b[k])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 """Host harness rows (SURVEY.md §2 ★ host harness): batch assembly of interpolate_single / interpolate,
 the warm-up toggling rule and the CFG combine of loop.py — CPU only, the UNet is a recording stub."""
 import numpy as np
+import pytest
 import torch
 
 import cases as C
@@ -38,6 +39,22 @@ def test_prepare_sequence_with_guide_prompt_shares_interior_context():
     assert all(torch.equal(b.uncond[i], ug[0]) for i in range(1, 6))
     assert b.ctx_index.tolist() == [0, 1, 1, 1, 1, 1, 2] and b.n_distinct_ctx == 3
     assert b.coef[0] == 0 and b.coef[-1] == 1 and abs(float(b.coef[3]) - 0.5) < 1e-6
+    cond3, unc3, idx = S.distinct_contexts(b)
+    assert idx == [0, 1, 1, 1, 1, 1, 2] and cond3.shape == (3, 7, 12)
+    assert torch.equal(cond3[idx], b.cond) and torch.equal(unc3[idx], b.uncond)
+
+
+def test_shared_context_map_validation():
+    from aid_amd.processors import _shared_context
+    ctx3 = torch.randn(3, 5, 8)
+    full = ctx3[[0, 1, 1, 2]]
+    c, m, idx = _shared_context({}, [0, 1, 1, 2], ctx3, 4)
+    assert torch.equal(c, ctx3) and m.tolist() == [0, 1, 1, 2] and m.dtype == torch.int32 and idx == [0, 1, 1, 2]
+    c2, _, _ = _shared_context({}, torch.tensor([0, 1, 1, 2]), full, 4)          # repeated rows in: de-duplicated
+    assert torch.equal(c2, ctx3)
+    for bad, ctx, n in (([0, 1, 1], ctx3, 4), ([0, 2, 2, 3], ctx3, 4), ([0, 1, 1, 2], ctx3[:2], 4), ([-1, 0, 0, 1], ctx3, 4)):
+        with pytest.raises(RuntimeError):
+            _shared_context({}, bad, ctx, n)
 
 
 def test_prepare_single_batch3_layout():
@@ -61,6 +78,7 @@ class _RecordingUNet(torch.nn.Module):
         super().__init__()
         self.inner = aid_amd.AttnStackUNet("sd15", dtype=torch.float32, scale_down=64, channel_div=8)
         self.calls = []
+        self.ctx_indices = []
 
     @property
     def attn_processors(self):
@@ -72,6 +90,7 @@ class _RecordingUNet(torch.nn.Module):
     def forward(self, sample, ctx):
         p = next(iter(self.attn_processors.values()))
         self.calls.append((p.activated, p.plain_tail, sample.shape[0], ctx.shape[0]))
+        self.ctx_indices.append(p.ctx_index)
         return sample * (2.0 if p.activated else 1.0) + ctx.mean()
 
 
@@ -98,3 +117,18 @@ def test_loop_toggling_follows_root_pipeline_rule():
     assert unet.calls == [(i < 3, 5 if i < 3 else 0, 10, 10) for i in range(7)]
     set_aid_active(unet, True)
     assert all(p.activated and p.plain_tail == 0 for p in unet.attn_processors.values())
+    # shared contexts: the loop hands the DISTINCT contexts to the UNet and the frame -> row map to every processor
+    unet.calls.clear(); unet.ctx_indices.clear()
+    idx = [0, 1, 1, 1, 2]
+    loop3 = AidDenoiseLoop(unet, x, cond[:3], uncond[:3], num_inference_steps=7, use_graphs=False, batched_cfg=True,
+                           ctx_index=idx)
+    loop3.step(0)
+    assert unet.calls == [(True, 5, 10, 6)] and unet.ctx_indices == [idx + [3, 4, 4, 4, 5]]
+    loop4 = AidDenoiseLoop(unet, x, cond[:3], uncond[:3], num_inference_steps=7, use_graphs=False, ctx_index=idx)
+    loop4.step(6)
+    assert unet.calls[1:] == [(False, 0, 5, 3)] * 2 and unet.ctx_indices[1:] == [idx, idx]
+    assert all(p.original_attn.ctx_index == idx for p in unet.attn_processors.values())
+    with pytest.raises(ValueError):
+        AidDenoiseLoop(unet, x, cond[:3], uncond[:3], use_graphs=False)            # 3 contexts for 5 frames, no map
+    with pytest.raises(ValueError):
+        AidDenoiseLoop(unet, x, cond[:3], uncond[:3], use_graphs=False, ctx_index=[0, 1, 2])
