@@ -413,8 +413,16 @@ struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
     static constexpr size_t SMEM = Base::SMEM;
     using Base::smem; using Base::tid; using Base::lane; using Base::wave; using Base::wm; using Base::wn;
     using Base::l31; using Base::hi; using Base::aoff; using Base::boff; using Base::ax; using Base::bx;
-    using Base::asrc; using Base::bsrc; using Base::acc;
+    using Base::acc;
+    typedef __amdgpu_buffer_rsrc_t Rsrc;
     int wr;
+    // DMA source addressing: one buffer resource per operand tile (base = first row of the tile) + a 32-bit byte
+    // offset per lane + the K position as scalar offset.  A `buffer_load ... lds` hands the address unit 4 B per
+    // lane and needs no VALU; the flat form (64-bit address per lane, v_lshl_add_u64 per DMA) kept the SIMD's issue
+    // busy ~29 cycles per DMA — with 16 DMAs per K tile and SIMD that was +20 % on the MFMA-bound loop (PMC:
+    // SQ_ACTIVE_INST_ANY, profiles/r01_gemm_variants.txt).
+    Rsrc ra, rb;
+    int avo[4], bvo[4];
 
     static __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 
@@ -446,11 +454,13 @@ struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
             for (int j = 0; j < 2; ++j) {
                 const int lrow = 8 * (2 * wave + j) + (lane >> 3);
                 const int c = (lane & 7) ^ swz(lrow);
-                const int ra = (lrow >> 6) * 128 + h * 64 + (lrow & 63);
-                const int cb = (lrow >> 5) * 64 + h * 32 + (lrow & 31);
-                asrc[h * 2 + j] = A + (int64_t)min(m0 + ra, P.m - 1) * P.lda + c * 8;
-                bsrc[h * 2 + j] = B + (int64_t)min(n0 + cb, P.n - 1) * P.ldb + c * 8;
+                const int row_a = (lrow >> 6) * 128 + h * 64 + (lrow & 63);
+                const int row_b = (lrow >> 5) * 64 + h * 32 + (lrow & 31);
+                avo[h * 2 + j] = min(row_a, P.m - 1 - m0) * (P.lda * 2) + c * 16;     // clamp: rows past the edge are never stored
+                bvo[h * 2 + j] = min(row_b, P.n - 1 - n0) * (P.ldb * 2) + c * 16;
             }
+        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A + (int64_t)m0 * P.lda), 0, 0x7fffffff, 0x00020000);
+        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(B + (int64_t)n0 * P.ldb), 0, 0x7fffffff, 0x00020000);
     }
 
     // DMA j (0 / 1) of half-tile Q: 0 = B0, 1 = B1, 2 = A0, 3 = A1
@@ -459,9 +469,8 @@ struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
         constexpr bool IS_A = Q >= 2;
         constexpr int H = Q & 1;
         char* dst = smem + parity * STG + (IS_A ? 0 : 2 * HALF) + H * HALF + wave * 2048 + j * 1024;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)((IS_A ? asrc[H * 2 + j] : bsrc[H * 2 + j]) + k0),
-            (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_A ? ra : rb, (__attribute__((address_space(3))) void*)dst, 16,
+                                                 IS_A ? avo[H * 2 + j] : bvo[H * 2 + j], k0 * 2, 0, 0);
     }
 
     static constexpr int E = 6;             // items of lead; a buffer is refilled >= 1 phase after its last read
