@@ -77,6 +77,7 @@ struct OState {
     bool   fresh;                       // no tile processed yet: the first tile sets the reference
     f32x16 o[NDB];
     f32x16 ol[XL ? 1 : 1];              // only used when XL
+    f32x16 cn;                          // -m in all 16 registers (C operand of the first MFMA), kept when PERSIST_C
 };
 
 typedef __amdgpu_buffer_rsrc_t Rsrc;
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     // row of ones in V^T -> the row sums l come out of the second MFMA as a row of O^T.  A spare padded row
     // (index D) exists for d = 40 / 80; d = 64 / 160 use one eXtra 32-row block fed from a constant fragment.
     constexpr bool XL = (D == DV);
+    constexpr bool PERSIST_C = D <= 64;         // 16 (plain / inner) or 32 (outer: two live states) more VGPRs
     constexpr int LBLK = D / 32, LREG = ((D % 32) / 8) * 4;     // (block, register) of row D at lanes hi == 0
     static_assert(XL || ((D % 32) % 8 == 0 && (D % 32) < 32), "spare row must sit at a register boundary");
     // head-room (log2) of P = 2^x in the storage type before the row reference has to be raised
@@ -296,9 +298,15 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             constexpr bool FULL = decltype(full_tag)::value;
             const int nb = FULL ? 2 : ((L - key0 > 32) ? 2 : 1);   // 32-key blocks with any valid key
             // x^T = K Q'^T - m : the accumulator starts at -m, so the MFMA result is the exponent argument
+            // (kept in registers across tiles where the budget allows: re-broadcasting it costs 16 v_mov per tile, a
+            // sixth of the VALU instructions of a kernel that is VALU-issue bound — profiles/r01_attn_notes.txt)
             f32x16 cneg;
+            if (PERSIST_C) {
+                cneg = st.cn;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cneg[r] = -st.m;
+                for (int r = 0; r < 16; ++r) cneg[r] = -st.m;
+            }
             f32x16 sc[2];
             const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
             // k-step outer, key-block inner: consecutive MFMAs go to DIFFERENT accumulators, so the dependent
@@ -346,6 +354,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 const float alpha = __builtin_amdgcn_exp2f(-shift);
                 st.m += shift;
                 st.fresh = false;
+                if (PERSIST_C) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st.cn[r] = -st.m;
+                    asm volatile("" : "+v"(st.cn));        // opaque: keeps the compiler from re-deriving it from m per tile
+                }
 #pragma unroll
                 for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -443,6 +456,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     auto init = [&](OState<NDB, XL>& st) {
         st.m = 0.f;
         st.fresh = true;
+        st.cn = zero16();
+        if (PERSIST_C) asm volatile("" : "+v"(st.cn));
 #pragma unroll
         for (int d = 0; d < NDB; ++d) st.o[d] = zero16();
         st.ol[0] = zero16();
