@@ -695,6 +695,7 @@ template <typename T>
 static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl) {
     static bool attr_set = false;
     if (pl.tiles <= 0) return hipSuccess;
+    if (plan_tiles(g, 256, 256) != pl.tiles) return hipErrorInvalidValue;      // g.tile_start must be in 256 x 256 units
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(aid_gemm_nt_pp_kernel<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PingPong<T>::SMEM);
@@ -732,8 +733,8 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** var
     PpPlan pl = {};
     if (!g.interleave && g.n_problems > 0) {
         const int nk = g.p[0].k / 64;
-        pl = plan_pp(g, ncu, nk);
         const int t128 = plan_tiles(g, 128, 128);
+        pl = plan_pp(g, ncu, nk);                   // last: leaves g.tile_start in 256 x 256 units for launch_pp
         const double r128 = 0.5 * (double)((2 * t128 + 2 * ncu - 1) / (2 * ncu));       // rounds of 2 CUs-fulls, in halves
         const double cost_ls = 3.0 + r128 * (4.1 + 1.09 * nk);
         const double cost_pp = 5.0 + pl.rounds * (6.0 + 1.62 * nk);

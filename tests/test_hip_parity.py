@@ -344,6 +344,31 @@ def test_full_size_layer_properties(model, dtype):
     assert rel_l2(to_np64(o12), to_np64(o1) + to_np64(o2)) < 2 * TOL[dtype]                      # (c)
 
 
+@pytest.mark.parametrize("cross", [False, True], ids=["self", "cross"])
+def test_full_size_processor_call_sdxl_level2(cross):
+    """One whole processor call at the SDXL C = 1280 level with the batched-CFG batch of 14 frames (S = 1024, 20 heads):
+    the grouped q / k / V^T launch and the out projection run on the ping-pong GEMM engine here.  Frames 0, 3 (AID, fused
+    outer) and 9 (plain rider) against the fp64 oracle on the bf16-rounded inputs."""
+    dtype, n, s, c, heads, l, cc = torch.bfloat16, 7, 1024, 1280, 20, 77, 2048
+    g = torch.Generator().manual_seed(1280)
+    attn = aid_amd.AttnShim(c, heads, cc if cross else None, dtype=dtype, device=DEV)
+    x = torch.randn(2 * n, s, c, generator=g).to(dtype)
+    ctx = torch.randn(2 * n, l, cc, generator=g).to(dtype) if cross else None
+    proc = aid_amd.OuterInterpolatedAttnProcessor(size=n, is_fused=True, alpha=50, beta=50)
+    proc.plain_tail = n
+    y = proc(attn, x.to(DEV), encoder_hidden_states=None if ctx is None else ctx.to(DEV))
+    assert ops.last_gemm_variant().startswith("pingpong256")                    # the out projection, at least
+    w = O.AttnWeights(*(to_np64(t) for t in (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
+                                              attn.to_out[0].weight, attn.to_out[0].bias)), heads)
+    coef = to_np64(proc.coef.to(dtype))
+    sel = [0, 3, n - 1]                                                          # begin, interior, end
+    xs, cs = to_np64(x[sel]), (None if ctx is None else to_np64(ctx[sel]))
+    ref = O.outer_attention(xs, cs, w, coef[sel], True)
+    assert rel_l2(to_np64(y[sel]), ref) < TOL[dtype]
+    refp = O.plain_attention(to_np64(x[n + 2:n + 3]), None if ctx is None else to_np64(ctx[n + 2:n + 3]), w)
+    assert rel_l2(to_np64(y[n + 2:n + 3]), refp) < TOL[dtype]
+
+
 # ------------------------------------------------------------------------------------------------
 # batched classifier-free guidance: [cond frames ; uncond frames] in ONE call (plain rider frames)
 # ------------------------------------------------------------------------------------------------
