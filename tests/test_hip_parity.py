@@ -369,6 +369,50 @@ def test_full_size_processor_call_sdxl_level2(cross):
     assert rel_l2(to_np64(y[n + 2:n + 3]), refp) < TOL[dtype]
 
 
+BENCH_LAYERS = [  # (model, dtype, S, C, heads, text width, mode, fused): every distinct attention layer of bench.py's two stacks
+    ("sd15", torch.float16, 4096, 320, 8, 768, "inner", True), ("sd15", torch.float16, 1024, 640, 8, 768, "inner", True),
+    ("sd15", torch.float16, 256, 1280, 8, 768, "inner", True), ("sd15", torch.float16, 64, 1280, 8, 768, "inner", True),
+    ("sdxl", torch.bfloat16, 4096, 640, 10, 2048, "outer", True), ("sdxl", torch.bfloat16, 1024, 1280, 20, 2048, "outer", True),
+]
+
+
+@pytest.mark.parametrize("cross", [False, True], ids=["self", "cross"])
+@pytest.mark.parametrize("layer", BENCH_LAYERS, ids=lambda t: f"{t[0]}_s{t[2]}_c{t[3]}")
+def test_every_bench_layer_at_full_size_vs_oracle(layer, cross):
+    """The exact calls bench.py times — 7 AID frames + 7 plain rider frames in one call, BetaPPF(50, 50) coefficients,
+    SDXL cross-attention with the PAID shared contexts — against the fp64 oracle on sampled query rows of the begin,
+    an interior and the end frame and of one rider frame.  (Whatever GEMM engine / attention variant the library
+    picks for these shapes is what gets checked.)"""
+    model, dtype, s, c, heads, cc, mode, fused = layer
+    n, l = 7, 77
+    g = torch.Generator().manual_seed(s + c + int(cross))
+    attn = aid_amd.AttnShim(c, heads, cc if cross else None, dtype=dtype, device=DEV)
+    x = torch.randn(2 * n, s, c, generator=g).to(dtype)
+    shared = cross and model == "sdxl"
+    idx = ([0] + [1] * (n - 2) + [2]) if shared else list(range(n))
+    idx2 = idx + [i + max(idx) + 1 for i in idx]
+    ctxd = torch.randn(max(idx2) + 1, l, cc, generator=g).to(dtype) if cross else None     # distinct contexts
+    cls = aid_amd.OuterInterpolatedAttnProcessor if mode == "outer" else aid_amd.InnerInterpolatedAttnProcessor
+    proc = cls(size=n, is_fused=fused, alpha=50, beta=50)
+    proc.plain_tail = n
+    y = proc(attn, x.to(DEV), encoder_hidden_states=None if ctxd is None else ctxd.to(DEV),
+             **({"ctx_index": idx2} if shared else {}))
+    w = O.AttnWeights(*(to_np64(t) for t in (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
+                                              attn.to_out[0].weight, attn.to_out[0].bias)), heads)
+    coef = to_np64(proc.coef.to(dtype))
+    rows = np.unique(np.concatenate([np.arange(0, s, max(s // 24, 1)), [31, 32, s - 1]])) if s > 64 else np.arange(s)
+
+    def oracle(frames, md, cf):
+        xs = to_np64(x[frames])
+        cs = None if ctxd is None else to_np64(ctxd[[idx2[f] for f in frames]])
+        q, k, v = O._project(xs, cs, w)
+        return O._out(O.attn_core(q[:, rows], k, v, heads, w.scale, md, fused and md != "plain", cf), w)
+
+    sel = [0, 3, n - 1]
+    assert rel_l2(to_np64(y[sel][:, rows]), oracle(sel, mode, coef[sel])) < TOL[dtype]
+    assert rel_l2(to_np64(y[n + 2:n + 3][:, rows]), oracle([n + 2], "plain", None)) < TOL[dtype]
+
+
 # ------------------------------------------------------------------------------------------------
 # batched classifier-free guidance: [cond frames ; uncond frames] in ONE call (plain rider frames)
 # ------------------------------------------------------------------------------------------------
