@@ -112,7 +112,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     // row of ones in V^T -> the row sums l come out of the second MFMA as a row of O^T.  A spare padded row
     // (index D) exists for d = 40 / 80; d = 64 / 160 use one eXtra 32-row block fed from a constant fragment.
     constexpr bool XL = (D == DV);
-    constexpr bool PERSIST_C = D <= 64;         // 16 (plain / inner) or 32 (outer: two live states) more VGPRs
+#ifndef AID_KPIPE
+#define AID_KPIPE 1
+#endif
+    constexpr bool KPIPE = AID_KPIPE != 0;
+    constexpr bool PERSIST_C = D <= 64 && !(KPIPE && D == 64 && MODE == AID_MODE_PLAIN);   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
     constexpr int LBLK = D / 32, LREG = ((D % 32) / 8) * 4;     // (block, register) of row D at lanes hi == 0
     static_assert(XL || ((D % 32) % 8 == 0 && (D % 32) < 32), "spare row must sit at a register boundary");
     // head-room (log2) of P = 2^x in the storage type before the row reference has to be raised
@@ -326,12 +330,35 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 }
             }
 #else
+            if (FULL && KPIPE) {
+                // K fragments two k-steps ahead of their MFMAs, order pinned: left to itself the compiler reuses ONE
+                // fragment register for all 2 NQK reads, i.e. a full LDS round trip in front of every MFMA
+                T8 kf[2][2];
+                kf[0][0] = *reinterpret_cast<const T8*>(kt);
+                kf[0][1] = *reinterpret_cast<const T8*>(kt + 32 * KLD);
+                if (NQK > 1) {
+                    kf[1][0] = *reinterpret_cast<const T8*>(kt + 16);
+                    kf[1][1] = *reinterpret_cast<const T8*>(kt + 32 * KLD + 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < NQK; ++ks) {
+                    sc[0] = mfma32(kf[ks & 1][0], qf[ks], ks ? sc[0] : cneg);
+                    sc[1] = mfma32(kf[ks & 1][1], qf[ks], ks ? sc[1] : cneg);
+                    if (ks + 2 < NQK) {
+                        kf[ks & 1][0] = *reinterpret_cast<const T8*>(kt + (ks + 2) * 16);
+                        kf[ks & 1][1] = *reinterpret_cast<const T8*>(kt + 32 * KLD + (ks + 2) * 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             sc[0] = mfma32(*reinterpret_cast<const T8*>(kt), qf[0], cneg);
             sc[1] = (FULL || nb > 1) ? mfma32(*reinterpret_cast<const T8*>(kt + 32 * KLD), qf[0], cneg) : cneg;
 #pragma unroll
             for (int ks = 1; ks < NQK; ++ks) {
                 sc[0] = mfma32(*reinterpret_cast<const T8*>(kt + ks * 16), qf[ks], sc[0]);
                 if (FULL || nb > 1) sc[1] = mfma32(*reinterpret_cast<const T8*>(kt + 32 * KLD + ks * 16), qf[ks], sc[1]);
+            }
             }
 #endif
             // lane (q, hi): sc[b][r] belongs to key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
