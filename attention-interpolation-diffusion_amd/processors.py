@@ -83,13 +83,19 @@ class InterpolatedAttnProcessor(nn.Module):
         key = (id(coef), coef._version, device, dtype, self.plain_tail)
         hit = self._coef_cache.get(key)
         if hit is None:
-            self._coef_cache.clear()
+            # entries are never dropped while they may be referenced: a captured hipGraph keeps reading the device
+            # tensor it was captured with (the loop alternates between a few (schedule, plain_tail) combinations)
+            if len(self._coef_cache) >= _CACHE_ENTRIES:
+                self._coef_cache.pop(next(iter(self._coef_cache)))
             hit = coef.detach().to(torch.float32).to(dtype).to(torch.float32)
             if self.plain_tail:                       # negative coefficient = PLAIN rider frame (aid_hip.h)
                 hit = torch.cat([hit, -torch.ones(self.plain_tail)])
             hit = hit.to(device).contiguous()
             self._coef_cache[key] = hit
         return hit
+
+
+_CACHE_ENTRIES = 16      # distinct (schedule, plain_tail) / context maps a processor keeps resident on the device
 
 
 def _shared_context(cache: Dict, ctx_index, ctx: torch.Tensor, batch: int):
@@ -103,7 +109,8 @@ def _shared_context(cache: Dict, ctx_index, ctx: torch.Tensor, batch: int):
     key = (tuple(idx), ctx.device)
     hit = cache.get(key)
     if hit is None:
-        cache.clear()
+        if len(cache) >= _CACHE_ENTRIES:          # see _coef_device: captured graphs hold on to these tensors
+            cache.pop(next(iter(cache)))
         first = [idx.index(r) for r in range(n_distinct)]
         hit = (torch.tensor(idx, dtype=torch.int32, device=ctx.device),
                torch.tensor(first, dtype=torch.long, device=ctx.device))
