@@ -49,9 +49,6 @@
 
 #include <type_traits>
 
-#ifndef AID_ABL
-#define AID_ABL 0      // development only: timing ablations of the tile loop (tools/ablate.sh); 0 = product
-#endif
 
 #include "aid_common.hpp"
 #include "aid_kernels.hpp"
@@ -112,10 +109,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     // row of ones in V^T -> the row sums l come out of the second MFMA as a row of O^T.  A spare padded row
     // (index D) exists for d = 40 / 80; d = 64 / 160 use one eXtra 32-row block fed from a constant fragment.
     constexpr bool XL = (D == DV);
-#ifndef AID_KPIPE
-#define AID_KPIPE 1
-#endif
-    constexpr bool KPIPE = AID_KPIPE != 0;
+    constexpr bool KPIPE = true;                // K fragment reads two k-steps ahead of their MFMAs (see tile())
     constexpr bool PERSIST_C = D <= 64 && !(KPIPE && D == 64 && MODE == AID_MODE_PLAIN);   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
     constexpr int LBLK = D / 32, LREG = ((D % 32) / 8) * 4;     // (block, register) of row D at lanes hi == 0
     static_assert(XL || ((D % 32) % 8 == 0 && (D % 32) < 32), "spare row must sit at a register boundary");
@@ -315,21 +309,6 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
             // k-step outer, key-block inner: consecutive MFMAs go to DIFFERENT accumulators, so the dependent
             // chain of one block never stalls the matrix pipe (the block-outer order measured ~45 % of the tile time)
-#if AID_ABL == 2
-            sc[0] = cneg; sc[1] = cneg;
-#elif AID_ABL == 6                       // block-outer order (the original): one dependent chain after the other
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                if (FULL || b < nb) {
-                    sc[b] = mfma32(*reinterpret_cast<const T8*>(kt + b * 32 * KLD), qf[0], cneg);
-#pragma unroll
-                    for (int ks = 1; ks < NQK; ++ks)
-                        sc[b] = mfma32(*reinterpret_cast<const T8*>(kt + b * 32 * KLD + ks * 16), qf[ks], sc[b]);
-                } else {
-                    sc[b] = cneg;
-                }
-            }
-#else
             if (FULL && KPIPE) {
                 // K fragments two k-steps ahead of their MFMAs, order pinned: left to itself the compiler reuses ONE
                 // fragment register for all 2 NQK reads, i.e. a full LDS round trip in front of every MFMA
@@ -360,7 +339,6 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 if (FULL || nb > 1) sc[1] = mfma32(*reinterpret_cast<const T8*>(kt + 32 * KLD + ks * 16), qf[ks], sc[1]);
             }
             }
-#endif
             // lane (q, hi): sc[b][r] belongs to key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
             if (!FULL) {
 #pragma unroll
@@ -407,11 +385,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     f32x8 pv;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-#if AID_ABL == 1
-                        pv[e] = sc[b][8 * u + e];
-#else
                         pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
-#endif
                     }
                     pf[2 * b + u] = cvt8<T>(pv);
                 }
@@ -419,12 +393,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             const T* vt = Vs + buf * DV * VLD + l31 * VLD + hi * 8;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-#if AID_ABL == 3
-                asm volatile("" ::"v"(pf[kk]));
-                if (false) {
-#else
                 if (FULL || kk < 2 * nb) {
-#endif
 #pragma unroll
                     for (int d = 0; d < NDB; ++d)
                         st.o[d] = mfma32(*reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16), pf[kk], st.o[d]);
@@ -445,11 +414,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         int t = 0;
         for (; t < nfull; ++t) {                        // tiles with all 64 keys valid: no masks, no edge logic
             const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
-#if AID_ABL == 4
-            if (false) {
-#else
             if (PREFETCH) {
-#endif
                 if (t + 1 < nfull)   stage_load(key0 + KT, std::true_type{});
                 else if (t + 1 < nt) stage_load(key0 + KT, std::false_type{});
             } else {
@@ -457,17 +422,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 __syncthreads();
             }
             tile(buf, key0, std::true_type{});
-#if AID_ABL == 4
-            if (false) {
-#else
             if (PREFETCH) {
-#endif
                 if (t + 1 < nfull)   stage_write(buf ^ 1, key0 + KT, std::true_type{});
                 else if (t + 1 < nt) stage_write(buf ^ 1, key0 + KT, std::false_type{});
             }
-#if AID_ABL != 5
             __syncthreads();
-#endif
         }
         if (t < nt) {                                   // ragged last tile
             const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
