@@ -74,6 +74,43 @@ def test_gemm_engine_selection_and_parity(dtype, mnk, engine):
     assert (col > 0.8).all() and (col < 1.25).all()
 
 
+def test_grouped_gemm_randomized_shapes_both_engines():
+    """Seeded sweep over grouped launches (1-3 problems, batched operands, ragged m / n, equal and different K loops, both
+    engines forced in turn where they apply) against fp32 torch matmuls of the same rounded operands on the GPU —
+    a second, independent reference next to the fp64 oracle tests; catches tile-mapping mistakes at sizes the
+    oracle is too slow for."""
+    rs = np.random.RandomState(950)
+    engines = set()
+    for it in range(36):
+        dtype = DTYPES[it % 2]
+        k_common = int(rs.choice([64, 128, 320, 640, 1280]))
+        nprob = int(rs.randint(1, 4))
+        same_k = bool(rs.randint(0, 2)) or nprob == 1
+        big = it % 3 == 0                                   # every third launch is large enough for the 256 x 256 engine
+        probs, refs = [], []
+        for p in range(nprob):
+            k = k_common if same_k else int(rs.choice([64, 192, 768, 2048]))
+            batch = int(rs.choice([1, 1, 3]))
+            m = int(rs.randint(2000, 40000)) if (big and batch == 1) else int(rs.randint(1, 1500))
+            n = int(rs.choice([8, 72, 128, 320, 504, 640, 1280]))
+            a = (torch.randn(batch, m, k, device=DEV) * 0.5).to(dtype)
+            b = (torch.randn(n, k, device=DEV) / k ** 0.5).to(dtype)
+            bias = torch.randn(n, device=DEV).to(dtype) if rs.randint(0, 2) else None
+            c = torch.full((batch, m, n), float("nan"), device=DEV, dtype=dtype)
+            probs.append(dict(a=a, b=b, c=c, bias=bias, m=m, n=n, k=k, lda=k, ldb=k, ldc=n, batch=batch,
+                              stride_a=m * k, stride_b=0, stride_c=m * n))
+            ref = a.float() @ b.float().t()
+            refs.append(ref if bias is None else ref + bias.float())
+        ops.gemm_nt(probs)
+        engines.add(ops.last_gemm_variant())
+        for p, ref in zip(probs, refs):
+            got = p["c"].float()
+            assert torch.isfinite(got).all(), (it, ops.last_gemm_variant())
+            err = ((got - ref).norm() / ref.norm()).item()
+            assert err < TOL_GEMM[dtype], (it, ops.last_gemm_variant(), p["m"], p["n"], p["k"], p["batch"], err)
+    assert {"lockstep128", "pingpong256"} <= {e.split("+")[0] for e in engines}, engines
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
 @pytest.mark.parametrize("shape", [(3, 77, 96, 80), (7, 200, 64, 128), (2, 5, 8, 40)])
 def test_kv_projection_writes_transposed_values_and_zero_padding(dtype, shape):
