@@ -15,14 +15,14 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AID_LIB_PATH") or os.path.join(PKG_DIR, "libaid_hip.so")   # override: development A/B builds
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
-AID_ABI_VERSION = 1
+AID_ABI_VERSION = 2
 DTYPE_F16, DTYPE_BF16 = 0, 1
 MODE_PLAIN, MODE_INNER, MODE_OUTER = 0, 1, 2
 GEMM_MAX_PROBLEMS = 4
 
 # every symbol include/aid_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "aid_gemm_nt", "aid_attn_fwd", "aid_lerp_kv", "aid_processor_workspace_bytes", "aid_processor_fwd",
+    "aid_gemm_nt", "aid_layernorm", "aid_attn_fwd", "aid_lerp_kv", "aid_processor_workspace_bytes", "aid_processor_fwd",
     "aid_abi_version", "aid_strerror", "aid_last_attn_variant", "aid_last_gemm_variant", "aid_device_info",
     "aid_profile_begin", "aid_profile_end",
 )
@@ -35,6 +35,7 @@ class AidGemmProblem(C.Structure):
         ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
         ("batch", C.c_int32), ("scale", C.c_float),
         ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64),
+        ("residual", C.c_void_p),
     ]
 
 
@@ -63,7 +64,8 @@ class AidProcessorArgs(C.Structure):
         ("cc", C.c_int32), ("heads", C.c_int32), ("mode", C.c_int32), ("fused", C.c_int32),
         ("begin", C.c_int32), ("end", C.c_int32), ("dtype", C.c_int32), ("n_ctx", C.c_int32),
         ("ctx_map", C.c_void_p),
-        ("n_plain", C.c_int32), ("_pad", C.c_int32),
+        ("n_plain", C.c_int32), ("ln_eps", C.c_float),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("residual", C.c_void_p),
     ]
 
 
@@ -105,6 +107,9 @@ def load() -> C.CDLL:
     lib.aid_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p]
     lib.aid_gemm_nt.restype = C.c_int
     lib.aid_gemm_nt.argtypes = [C.POINTER(AidGemmProblem), C.c_int, C.c_int, C.c_void_p]
+    lib.aid_layernorm.restype = C.c_int
+    lib.aid_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                  C.c_int32, C.c_void_p]
     lib.aid_attn_fwd.restype = C.c_int
     lib.aid_attn_fwd.argtypes = [C.POINTER(AidAttnArgs), C.c_void_p]
     lib.aid_lerp_kv.restype = C.c_int

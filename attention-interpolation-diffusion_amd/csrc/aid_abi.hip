@@ -63,7 +63,7 @@ int check_problem(const AidGemmProblem& q) {
 }
 
 struct Carve {
-    size_t q, k, vt, o, k2, vt2, total;
+    size_t q, k, vt, o, k2, vt2, xn, total;
     int lp;
 };
 
@@ -83,6 +83,8 @@ Carve carve(const AidProcessorArgs& a) {
         c.k2 = off;  off += align_up((size_t)a.n_frames * l * a.c * es, 256);
         c.vt2 = off; off += align_up((size_t)a.n_frames * a.c * c.lp * es, 256);
     }
+    c.xn = off;
+    if (a.ln_eps > 0.f) off += align_up((size_t)a.n_frames * a.s * a.c * es, 256);     // LayerNorm(x)
     c.total = off;
     return c;
 }
@@ -103,6 +105,11 @@ int check_processor(const AidProcessorArgs& a) {
         return AID_ERR_ARG;
     }
     if (a.mode != AID_MODE_PLAIN && (a.begin < 0 || a.begin >= nctx || a.end < 0 || a.end >= nctx)) return AID_ERR_ARG;
+    if (!(a.ln_eps >= 0.f)) return AID_ERR_ARG;
+    if (a.ln_eps > 0.f) {
+        if (!aid::layernorm_width_supported(a.c)) return AID_ERR_SHAPE;
+        if ((a.ln_gamma && !aligned16(a.ln_gamma)) || (a.ln_beta && !aligned16(a.ln_beta))) return AID_ERR_SHAPE;
+    }
     return AID_OK;
 }
 
@@ -180,7 +187,7 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
         int rc = check_problem(q);
         if (rc != AID_OK) return rc;
         aid::GemmDesc& d = g.p[i];
-        d.a = q.a; d.b = q.b; d.c = q.c; d.bias = q.bias;
+        d.a = q.a; d.b = q.b; d.c = q.c; d.bias = q.bias; d.residual = q.residual;
         d.m = q.m; d.n = q.n; d.k = q.k;
         d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc;
         d.batch = q.batch;
@@ -193,7 +200,8 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
             const AidGemmProblem& q = problems[i];
             flops += 2.0 * q.m * q.n * q.k * q.batch;
             bytes += 2.0 * ((double)q.m * q.k * (q.stride_a || q.batch == 1 ? q.batch : 1) +
-                            (double)q.n * q.k * (q.stride_b || q.batch == 1 ? q.batch : 1) + (double)q.m * q.n * q.batch);
+                            (double)q.n * q.k * (q.stride_b || q.batch == 1 ? q.batch : 1) +
+                            (double)q.m * q.n * q.batch * (q.residual ? 2 : 1));
         }
     }
     hipError_t e;
@@ -203,6 +211,21 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
         e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream), &g_gemm_variant);
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_gemm_nt");
+}
+
+int aid_layernorm(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c, float eps,
+                  int32_t dtype, void* stream) {
+    if (!x || !y || rows < 0 || !(eps >= 0.f)) return AID_ERR_ARG;
+    if (dtype != AID_DTYPE_F16 && dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (!aid::layernorm_width_supported(c)) return AID_ERR_SHAPE;
+    if (!aligned16(x) || !aligned16(y) || (gamma && !aligned16(gamma)) || (beta && !aligned16(beta))) return AID_ERR_SHAPE;
+    hipError_t e;
+    {
+        ProfScope ps(static_cast<hipStream_t>(stream), dtype == AID_DTYPE_F16 ? "aid_layernorm<f16>" : "aid_layernorm<bf16>",
+                     8.0 * rows * c, 4.0 * rows * c);
+        e = aid::layernorm_launch(x, gamma, beta, y, rows, c, eps, dtype, static_cast<hipStream_t>(stream));
+    }
+    return e == hipSuccess ? AID_OK : fail_hip(e, "aid_layernorm");
 }
 
 int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
@@ -277,7 +300,14 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     void* vt = ws + cv.vt;
     void* o = ws + cv.o;
     const bool cross = a.ctx != nullptr;
-    const void* e = cross ? a.ctx : a.x;
+    const void* xin = a.x;
+    if (a.ln_eps > 0.f) {                      // 0. the block's norm1 / norm2 in front of the call
+        void* xn = ws + cv.xn;
+        rc = aid_layernorm(a.x, a.ln_gamma, a.ln_beta, xn, (int64_t)a.n_frames * a.s, a.c, a.ln_eps, a.dtype, stream);
+        if (rc != AID_OK) return rc;
+        xin = xn;
+    }
+    const void* e = cross ? a.ctx : xin;
     const int nctx = cross ? a.n_ctx : a.n_frames;
     const int l = cross ? a.l : a.s;
     const int cc = cross ? a.cc : a.c;
@@ -286,7 +316,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     // 1. q, k and V^T projections in one grouped launch
     AidGemmProblem pr[3];
     memset(pr, 0, sizeof(pr));
-    pr[0].a = a.x;  pr[0].b = a.wq; pr[0].c = q;
+    pr[0].a = xin;  pr[0].b = a.wq; pr[0].c = q;
     pr[0].m = a.n_frames * a.s; pr[0].n = a.c; pr[0].k = a.c;
     pr[0].lda = a.c; pr[0].ldb = a.c; pr[0].ldc = a.c; pr[0].batch = 1;
     pr[0].scale = 1.4426950408889634f / sqrtf((float)d);      // softmax_scale * log2(e) folded into q before its rounding
@@ -329,7 +359,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     // 3. out projection + bias
     AidGemmProblem po;
     memset(&po, 0, sizeof(po));
-    po.a = o; po.b = a.wo; po.c = a.y; po.bias = a.bo;
+    po.a = o; po.b = a.wo; po.c = a.y; po.bias = a.bo; po.residual = a.residual;
     po.m = a.n_frames * a.s; po.n = a.c; po.k = a.c;
     po.lda = a.c; po.ldb = a.c; po.ldc = a.c; po.batch = 1;
     return aid_gemm_nt(&po, 1, a.dtype, stream);

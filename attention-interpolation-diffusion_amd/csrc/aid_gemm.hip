@@ -190,6 +190,12 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_kernel(const GemmGroup g
                     for (int e = 0; e < 4; ++e)
                         if (n + e < P.n) v[e] += (float)bias[n + e];
                 }
+                if (P.residual) {                       // added after the first rounding, like the reference's separate add
+                    const T* R = reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c + (int64_t)m * P.ldc + n;
+                    const f32x4 r0 = up4<T>(cvt4<T>(v));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (n + e < P.n) ? r0[e] + (float)R[e] : 0.f;
+                }
                 *reinterpret_cast<T4*>(C + (int64_t)m * P.ldc + n) = cvt4<T>(v);
             }
         }
@@ -342,7 +348,8 @@ struct Engine {
     }
 
     // acc (+bias) -> LDS C tile -> coalesced 16-B row segments.  Ends with all stores drained and a barrier.
-    __device__ __forceinline__ void store_tile(const GemmDesc& P, T* C, int m0, int n0) {
+    // `R` (optional, laid out like C) is added after the rounding to T — the transformer block's residual add.
+    __device__ __forceinline__ void store_tile(const GemmDesc& P, T* C, int m0, int n0, const T* R = nullptr) {
         T* Cs = reinterpret_cast<T*>(smem);        // [BM][CLD]
         const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
         const bool bias_vec = (reinterpret_cast<uintptr_t>(bias) & 7) == 0;
@@ -378,14 +385,27 @@ struct Engine {
             const int row = id / CPRW, ch = (id % CPRW) * 8;
             const int m = m0 + row, n = n0 + ch;
             if (m >= P.m || n >= P.n) continue;
-            const T8 v = *reinterpret_cast<const T8*>(Cs + row * CLD + ch);
+            T8 v = *reinterpret_cast<const T8*>(Cs + row * CLD + ch);
             T* dst = C + (int64_t)m * P.ldc + n;
+            const T* res = R ? R + (int64_t)m * P.ldc + n : nullptr;
             if (vec_ok && n + 8 <= P.n) {
+                if (res) {
+                    const bool rvec = (reinterpret_cast<uintptr_t>(R) & 15) == 0;
+                    T8 r;
+                    if (rvec) {
+                        r = *reinterpret_cast<const T8*>(res);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) r[e] = res[e];
+                    }
+                    const f32x8 a = up8<T>(v), b = up8<T>(r);
+                    v = cvt8<T>(a + b);
+                }
                 *reinterpret_cast<T8*>(dst) = v;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (n + e < P.n) dst[e] = v[e];
+                    if (n + e < P.n) dst[e] = res ? (T)((float)v[e] + (float)res[e]) : v[e];
             }
         }
     }
@@ -588,7 +608,7 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         e.set_tile(P, A, B, tc.m0, tc.n0);
         e.zero_acc();
         e.mac(0, P.k / 64);
-        e.store_tile(P, C, tc.m0, tc.n0);
+        e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr);
     } else {
         const int u = b - n_big;                                   // n_big is a multiple of 8: u % 8 is still the XCD
         const int n_rest = (gridDim.x - n_big) >> 2;
@@ -606,7 +626,7 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         e.set_tile(P, A, B, tc.m0, tc.n0);
         e.zero_acc();
         e.mac(0, P.k / 64);
-        e.store_tile(P, C, tc.m0, tc.n0);
+        e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr);
     }
 }
 
@@ -624,7 +644,7 @@ __global__ __launch_bounds__(WM * WN * 64) void aid_gemm_nt_pipe_kernel(const Ge
     e.set_tile(P, A, B, tc.m0, tc.n0);
     e.zero_acc();
     e.mac(0, P.k / BK);
-    e.store_tile(P, C, tc.m0, tc.n0);
+    e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

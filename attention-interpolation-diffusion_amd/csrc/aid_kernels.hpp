@@ -11,6 +11,7 @@ struct GemmDesc {
     const void* b;
     void*       c;
     const void* bias;
+    const void* residual;                             // added after the rounding of scale * A B^T + bias (NULL = none)
     int32_t m, n, k;
     int32_t lda, ldb, ldc;
     int32_t batch;
@@ -34,5 +35,8 @@ bool       attn_head_dim_supported(int d);
 hipError_t lerp_kv_launch(const void* k, const void* vt, void* k2, void* vt2, const float* coef, int n_frames, int begin,
                           int end, int64_t k_fs, int64_t vt_fs, int dtype, hipStream_t stream);
 const char* attn_variant_name(const AidAttnArgs& a);   // thread-local buffer
+hipError_t layernorm_launch(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int c, float eps,
+                            int dtype, hipStream_t stream);
+bool       layernorm_width_supported(int c);
 
 }  // namespace aid

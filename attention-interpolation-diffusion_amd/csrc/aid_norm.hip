@@ -1,0 +1,92 @@
+// LayerNorm over the channel dimension of [rows, c] activations — the `norm1` / `norm2` that sits in front of the
+// attention call inside diffusers' BasicTransformerBlock (the step either side of the path).
+// HBM-bound streaming: one wave per row, 16 B per lane per access, the row stays in registers between the
+// statistics and the normalisation (read once, written once), fp32 statistics with the two-pass variance
+// (sum of squared deviations), one rounding to the storage type — what torch's LayerNorm kernel produces for
+// fp16 / bf16 inputs up to the order of the fp32 reduction.
+#include "aid_common.hpp"
+#include "aid_kernels.hpp"
+
+namespace aid {
+
+constexpr int LN_MAX_CHUNKS = 4;            // 64 lanes x 8 elements x 4 = 2048 channels
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+    return sum_halves(v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void aid_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                            const T* __restrict__ beta, T* __restrict__ y, int64_t rows,
+                                                            int c, float eps) {
+    typedef typename Vec<T>::v8 T8;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = c >> 3;                                     // 16-B chunks per row
+    const T* xr = x + row * c;
+    f32x8 v[LN_MAX_CHUNKS];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            v[i] = up8<T>(*reinterpret_cast<const T8*>(xr + ch * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                q = fmaf(d, d, q);
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+    T* yr = y + row * c;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            f32x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd;
+            if (gamma) {
+                const f32x8 g = up8<T>(*reinterpret_cast<const T8*>(gamma + ch * 8));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] *= g[e];
+            }
+            if (beta) {
+                const f32x8 b = up8<T>(*reinterpret_cast<const T8*>(beta + ch * 8));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += b[e];
+            }
+            *reinterpret_cast<T8*>(yr + ch * 8) = cvt8<T>(o);
+        }
+    }
+}
+
+bool layernorm_width_supported(int c) { return c >= 8 && c % 8 == 0 && c <= 64 * 8 * LN_MAX_CHUNKS; }
+
+hipError_t layernorm_launch(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int c, float eps,
+                            int dtype, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == AID_DTYPE_F16)
+        hipLaunchKernelGGL(aid_layernorm_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)x, (const f16*)gamma,
+                           (const f16*)beta, (f16*)y, rows, c, eps);
+    else
+        hipLaunchKernelGGL(aid_layernorm_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)gamma,
+                           (const bf16*)beta, (bf16*)y, rows, c, eps);
+    return hipGetLastError();
+}
+
+}  // namespace aid

@@ -66,14 +66,15 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
 
 # ---------------------------------------------------------------------------------------------
 def gemm_nt(problems: Sequence[dict]) -> None:
-    """Grouped C = A @ B^T (+ bias).  Each problem: dict(a=[.., m, k], b=[n, k] or [batch, n, k],
-    c=out tensor, bias=None|[n], batch=1, m, n, k, lda, ldb, ldc, stride_a, stride_b, stride_c)."""
+    """Grouped C = A @ B^T (+ bias) (+ residual, added after the rounding).  Each problem: dict(a=[.., m, k],
+    b=[n, k] or [batch, n, k], c=out tensor, bias=None|[n], residual=None|like c, batch=1, m, n, k, lda, ldb, ldc,
+    stride_a, stride_b, stride_c)."""
     lib = _lib.load()
     n = len(problems)
     arr = (AidGemmProblem * n)()
     dt = None
     for i, p in enumerate(problems):
-        _require_gpu(p["a"], p["b"], p["c"], p.get("bias"))
+        _require_gpu(p["a"], p["b"], p["c"], p.get("bias"), p.get("residual"))
         code = _dtype_code(p["a"])
         if dt is None:
             dt = code
@@ -82,6 +83,7 @@ def gemm_nt(problems: Sequence[dict]) -> None:
         q = arr[i]
         q.a, q.b, q.c = p["a"].data_ptr(), p["b"].data_ptr(), p["c"].data_ptr()
         q.bias = _ptr(p.get("bias"))
+        q.residual = _ptr(p.get("residual"))
         q.m, q.n, q.k = p["m"], p["n"], p["k"]
         q.lda, q.ldb, q.ldc = p["lda"], p["ldb"], p["ldc"]
         q.batch = p.get("batch", 1)
@@ -90,15 +92,34 @@ def gemm_nt(problems: Sequence[dict]) -> None:
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x @ w.T + bias on the HIP GEMM (x [..., k] contiguous, w [n, k] contiguous)."""
+           out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ w.T + bias (+ residual) on the HIP GEMM (x [..., k] contiguous, w [n, k] contiguous)."""
     assert x.is_contiguous() and w.is_contiguous()
     k = x.shape[-1]
     n = w.shape[0]
     m = x.numel() // k
     if out is None:
         out = torch.empty(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
-    gemm_nt([dict(a=x, b=w, c=out, bias=bias, m=m, n=n, k=k, lda=k, ldb=k, ldc=n)])
+    if residual is not None and (residual.shape != out.shape or residual.dtype != out.dtype or not residual.is_contiguous()):
+        raise ValueError("residual must be a contiguous tensor shaped like the output")
+    gemm_nt([dict(a=x, b=w, c=out, bias=bias, residual=residual, m=m, n=n, k=k, lda=k, ldb=k, ldc=n)])
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+              eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm over the last dimension on the HIP kernel (fp32 statistics, one rounding)."""
+    _require_gpu(x, gamma, beta, out)
+    if not x.is_contiguous():
+        raise ValueError("operands must be contiguous")
+    for t_ in (gamma, beta):
+        if t_ is not None and (t_.dtype != x.dtype or t_.numel() != x.shape[-1] or not t_.is_contiguous()):
+            raise ValueError("gamma / beta must be contiguous [c] tensors of the activation dtype")
+    if out is None:
+        out = torch.empty_like(x)
+    c = x.shape[-1]
+    _lib.check(_lib.load().aid_layernorm(x.data_ptr(), _ptr(gamma), _ptr(beta), out.data_ptr(), x.numel() // c, c,
+                                         float(eps), _dtype_code(x), _stream()), "aid_layernorm")
     return out
 
 
@@ -181,11 +202,15 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
                   wv: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], heads: int, *,
                   mode: str = "plain", fused: bool = False, coef: Optional[torch.Tensor] = None,
                   begin: int = 0, end: int = -1, ctx_map: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None, n_plain: int = 0) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, n_plain: int = 0,
+                  ln: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor], float]] = None,
+                  residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One whole processor call: y = to_out(AID-attention(to_q(x), to_k(ctx), to_v(ctx)))
-    in three launches (grouped q/k/V^T GEMM, attention core, out-proj GEMM)."""
+    in three launches (grouped q/k/V^T GEMM, attention core, out-proj GEMM).
+    ``ln = (gamma, beta, eps)`` computes on LayerNorm(x); ``residual`` is added to the result (the transformer
+    block's norm in front of the call and its residual add after it)."""
     lib = _lib.load()
-    dev = _require_gpu(x, ctx, wq, wk, wv, wo, bo, coef, ctx_map, out)
+    dev = _require_gpu(x, ctx, wq, wk, wv, wo, bo, coef, ctx_map, out, residual, *(ln[:2] if ln else ()))
     dt = _dtype_code(x)
     for t_ in (ctx, wq, wk, wv, wo, bo):
         if t_ is not None and t_.dtype != x.dtype:
@@ -210,6 +235,18 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
     a.begin, a.end = begin % nkv, end % nkv
     a.dtype = dt
     a.n_plain = int(n_plain)
+    if ln is not None:
+        g_, b_, eps = ln
+        if not eps > 0:
+            raise ValueError("LayerNorm eps must be > 0")
+        for t_ in (g_, b_):
+            if t_ is not None and (t_.dtype != x.dtype or t_.numel() != c or not t_.is_contiguous()):
+                raise ValueError("LayerNorm gamma / beta must be contiguous [c] tensors of the activation dtype")
+        a.ln_gamma, a.ln_beta, a.ln_eps = _ptr(g_), _ptr(b_), float(eps)
+    if residual is not None:
+        if residual.shape != x.shape or residual.dtype != x.dtype or not residual.is_contiguous():
+            raise ValueError("residual must be a contiguous tensor shaped like the hidden states")
+        a.residual = residual.data_ptr()
     nbytes = lib.aid_processor_workspace_bytes(C.byref(a))
     if nbytes == 0:
         # let the library say why

@@ -71,6 +71,27 @@ class InterpolatedAttnProcessor(nn.Module):
         self.key_end = key_end
         self.value_end = value_end
 
+    # ---- build-specific: the step either side of the call ----------------------
+    _mode: Optional[str] = None          # "outer" / "inner" in the text subclasses
+
+    def fused_sublayer(self, attn, norm, hidden_states, encoder_hidden_states=None, ctx_index=None):
+        """``hidden_states + attn(norm(hidden_states), encoder_hidden_states)`` — what diffusers' BasicTransformerBlock
+        computes around attn1 / attn2 (LayerNorm, processor call, residual add) — in ONE library call: the LayerNorm
+        runs as a HIP kernel in front of the projections and the residual is added in the epilogue of the out
+        projection (after its rounding, so the result is bit-identical to the three separate steps on the same
+        kernels).  Falls back to the three steps where the one-call form does not apply (a wrapped foreign
+        ``original_attn``, 4-D inputs, Attention extras)."""
+        if self._mode is None:
+            raise NotImplementedError("fused_sublayer is implemented for the text processors (outer / inner)")
+        foreign = (not self.activated) and getattr(self, "original_attn", None) is not None \
+            and not isinstance(self.original_attn, HipAttnProcessor)
+        if foreign or not _plain_sublayer_ok(attn, hidden_states):
+            return hidden_states + self(attn, norm(hidden_states), encoder_hidden_states, ctx_index=ctx_index)
+        ctx_index = self.ctx_index if ctx_index is None else ctx_index
+        hidden_states = hidden_states.contiguous()
+        return _run_text(self, attn, hidden_states, encoder_hidden_states, None, None,
+                         self._mode if self.activated else "plain", ctx_index, ln=_ln_of(norm), add_to=hidden_states)
+
     # ---- build-specific helpers ------------------------------------------------------------
     def _coef_device(self, device: torch.device, dtype: torch.dtype, batch: int) -> torch.Tensor:
         """``coef.to(key.device, key.dtype)`` (interpolation.py:663: coefficients are rounded to
@@ -164,8 +185,23 @@ def _weights(attn):
     return attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, wo.weight, wo.bias
 
 
+def _ln_of(norm) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], float]:
+    """(gamma, beta, eps) of the torch LayerNorm that sits in front of an attention layer."""
+    if not isinstance(norm, nn.LayerNorm) or len(norm.normalized_shape) != 1:
+        raise TypeError("fused_sublayer needs the block's nn.LayerNorm over the channel dimension")
+    return norm.weight, norm.bias, float(norm.eps)
+
+
+def _plain_sublayer_ok(attn, hidden_states) -> bool:
+    """The one-call form  h + attn(norm(h))  covers the transformer-block attention of SD / SDXL: 3-D input and none of
+    the Attention extras (spatial / group norm, own residual connection, output rescale, cross-attention norm)."""
+    return (hidden_states.ndim == 3 and getattr(attn, "spatial_norm", None) is None
+            and getattr(attn, "group_norm", None) is None and not getattr(attn, "residual_connection", False)
+            and getattr(attn, "rescale_output_factor", 1.0) == 1.0 and not getattr(attn, "norm_cross", None))
+
+
 def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidden_states,
-              attention_mask, temb, mode: str, ctx_index=None):
+              attention_mask, temb, mode: str, ctx_index=None, ln=None, add_to=None):
     residual, x, ctx, shape4 = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
     wq, wk, wv, wo, bo = _weights(attn)
     coef = None
@@ -184,7 +220,7 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
     y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode,
                           fused=proc.is_fused if mode != "plain" else False, coef=coef,
                           begin=begin, end=end, ctx_map=ctx_map,
-                          n_plain=proc.plain_tail if mode != "plain" else 0)
+                          n_plain=proc.plain_tail if mode != "plain" else 0, ln=ln, residual=add_to)
     return _epilogue(attn, y, residual, shape4)
 
 
@@ -196,6 +232,21 @@ class HipAttnProcessor:
     def __init__(self):
         self.ctx_index: Optional[Sequence[int]] = None      # see InterpolatedAttnProcessor.ctx_index
         self._ctx_cache: Dict[Tuple, Tuple] = {}
+
+    def fused_sublayer(self, attn, norm, hidden_states, encoder_hidden_states=None, ctx_index=None):
+        """``hidden_states + attn(norm(hidden_states), ...)`` in one library call (see InterpolatedAttnProcessor)."""
+        if not _plain_sublayer_ok(attn, hidden_states):
+            return hidden_states + self(attn, norm(hidden_states), encoder_hidden_states, ctx_index=ctx_index)
+        x = hidden_states.contiguous()
+        wq, wk, wv, wo, bo = _weights(attn)
+        ctx, ctx_map = encoder_hidden_states, None
+        ctx_index = self.ctx_index if ctx_index is None else ctx_index
+        if ctx is not None and ctx_index is not None:
+            ctx, ctx_map, _ = _shared_context(self._ctx_cache, ctx_index, ctx, x.shape[0])
+        elif ctx is not None:
+            ctx = ctx.contiguous()
+        return ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map,
+                                 ln=_ln_of(norm), residual=x)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  *args, ctx_index=None, **kwargs):
@@ -215,6 +266,7 @@ class OuterInterpolatedAttnProcessor(InterpolatedAttnProcessor):
     r"""Outer attention interpolation (interpolation.py:548-679):
     (1 - t) * A(Q_t, K_1, V_1) + t * A(Q_t, K_m, V_m); fused with self-attention:
     (1 - t) * A(Q_t, [K_t, K_1], [V_t, V_1]) + t * A(Q_t, [K_t, K_m], [V_t, V_m])."""
+    _mode = "outer"
 
     def __init__(self, t: Optional[float] = None, size: int = 7, is_fused: bool = False,
                  alpha: float = 1, beta: float = 1, original_attn=None):
@@ -237,6 +289,7 @@ class OuterInterpolatedAttnProcessor(InterpolatedAttnProcessor):
 class InnerInterpolatedAttnProcessor(InterpolatedAttnProcessor):
     r"""Inner attention interpolation (interpolation.py:682-804): keys / values are interpolated
     between the end-point frames, A(Q_t, [K_t,] (1-t) K_1 + t K_m, [V_t,] (1-t) V_1 + t V_m)."""
+    _mode = "inner"
 
     def __init__(self, t: Optional[float] = None, size: int = 7, is_fused: bool = False,
                  alpha: float = 1, beta: float = 1, original_attn=None):

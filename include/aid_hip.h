@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AID_ABI_VERSION 1
+#define AID_ABI_VERSION 2
 
 /* element types of activations / weights (accumulation is always fp32) */
 #define AID_DTYPE_F16  0
@@ -58,6 +58,9 @@ extern "C" {
  *   C [m, n] row-major (ldc).  bias (optional) is indexed by n and has the operand dtype.
  *   Up to AID_GEMM_MAX_PROBLEMS independent problems run in ONE launch (q, k and V^T
  *   projections of an attention layer).
+ *   `residual` (optional, laid out like C incl. stride_c) is added AFTER the result was rounded to the
+ *   operand dtype: C = round(round(scale * A B^T + bias) + residual) — bit for bit the reference's separate
+ *   `hidden_states = attn_output + hidden_states` on the out-projection.
  *   Requirements: k % 8 == 0, lda % 8 == 0, ldb % 8 == 0, ldc % 4 == 0, ldc >= round_up(n, 4),
  *   all base pointers 16-byte aligned.  Columns [n, round_up(n,4)) of C are written with zeros.
  * ------------------------------------------------------------------------------------- */
@@ -73,9 +76,19 @@ typedef struct AidGemmProblem {
     int32_t     batch;         /* >= 1 */
     float       scale;         /* C = scale * (A B^T) + bias; 0 means 1 (zero-initialised structs)  */
     int64_t     stride_a, stride_b, stride_c;   /* per-batch strides in elements (0 = shared) */
+    const void* residual;      /* NULL = none; [m, ldc] per batch like C, operand dtype               */
 } AidGemmProblem;
 
 int aid_gemm_nt(const AidGemmProblem* problems /* host */, int n_problems, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension: y[r, :] = (x[r, :] - mean_r) * rsqrt(var_r + eps) * gamma + beta
+ * — the norm1 / norm2 in front of the attention call in diffusers' BasicTransformerBlock (the step
+ * before the path).  fp32 statistics, one rounding; gamma / beta may be NULL.
+ * Requirements: c % 8 == 0, 8 <= c <= 2048, x / y / gamma / beta 16-byte aligned, rows contiguous.
+ * ------------------------------------------------------------------------------------- */
+int aid_layernorm(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c,
+                  float eps, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Interpolated attention core on projected tensors.
@@ -141,8 +154,11 @@ int aid_lerp_kv(const void* k, const void* vt, void* k2, void* vt2, const float*
  *   x   [n_frames, s, c]   hidden states          ctx [n_frames, l, cc] or NULL (self-attn: ctx = x)
  *   wq [c, c]  wk [c, cc]  wv [c, cc]  wo [c, c]  bo [c]      (torch Linear.weight layout [out, in])
  *   y   [n_frames, s, c]   = to_out( AID-attention( to_q(x), to_k(ctx), to_v(ctx) ) )
- * Launches: 1 grouped GEMM (q, k, V^T), [INNER: 1 streaming K/V lerp,] 1 attention kernel,
- * 1 GEMM (out-proj + bias).
+ * Launches: [1 LayerNorm,] 1 grouped GEMM (q, k, V^T), [INNER: 1 streaming K/V lerp,] 1 attention kernel,
+ * 1 GEMM (out-proj + bias [+ residual]).
+ * Optional block-level fusion: with ln_eps > 0 the call computes on LayerNorm(x) (the block's
+ * norm1 / norm2; self-attention keys / values use the normalised x too, a cross-attention ctx is left alone), and
+ * with `residual` it returns  residual + to_out(...)  — together  h + attn(norm(h))  in one call.
  * `workspace` must hold aid_processor_workspace_bytes() bytes (16-byte aligned); it is
  * scratch, owned by the caller, and may be reused by the next call on the same stream.
  * ------------------------------------------------------------------------------------- */
@@ -166,7 +182,10 @@ typedef struct AidProcessorArgs {
     int32_t n_ctx;               /* number of ctx frames (n_frames, or fewer with ctx_map)   */
     const int32_t* ctx_map;      /* device [n_frames] frame -> ctx row, or NULL (identity)   */
     int32_t n_plain;             /* frames whose coef is negative (PLAIN riders), accounting  */
-    int32_t _pad;
+    float   ln_eps;              /* > 0: LayerNorm(x) over c first (gamma / beta below)       */
+    const void* ln_gamma;        /* [c] or NULL                                               */
+    const void* ln_beta;         /* [c] or NULL                                               */
+    const void* residual;        /* [n_frames, s, c] or NULL: added to y (may alias x)        */
 } AidProcessorArgs;
 
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args /* host */);

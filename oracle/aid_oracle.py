@@ -34,6 +34,7 @@ __all__ = [
     "outer_ip_attention", "inner_ip_attention", "scale_control_ip_attention",
     "attn_core", "slerp", "linear_interpolation", "spherical_interpolation",
     "next_exploration_t",
+    "layer_norm",
 ]
 
 
@@ -194,6 +195,20 @@ def _project(x, ctx, w: AttnWeights):
 
 def _out(o, w: AttnWeights):
     return linear(o, w.wo, w.bo)                        # interpolation.py:666-667 (dropout p=0)
+
+
+def layer_norm(x: np.ndarray, gamma: Optional[np.ndarray] = None, beta: Optional[np.ndarray] = None,
+               eps: float = 1e-5) -> np.ndarray:
+    """torch.nn.LayerNorm over the last dimension (biased variance) — the norm1 / norm2 of diffusers'
+    BasicTransformerBlock in front of attn1 / attn2 (third-party; the step before the path)."""
+    mu = x.mean(axis=-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+    y = (x - mu) / np.sqrt(var + eps)
+    if gamma is not None:
+        y = y * gamma
+    if beta is not None:
+        y = y + beta
+    return y
 
 
 def plain_attention(x, ctx, w: AttnWeights) -> np.ndarray:

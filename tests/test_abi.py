@@ -156,3 +156,25 @@ def test_interp_helpers_match_goldens():
     np.testing.assert_allclose(aid_amd.spherical_interpolation(v0, v1, 4).numpy(), misc["spherical_size4"], atol=2e-6)
     for n, a, b in ((7, 3, 3), (16, 50, 50), (5, 25, 25)):
         np.testing.assert_array_equal(aid_amd.generate_beta_tensor(n, a, b).numpy(), misc[f"beta_{n}_{a}_{b}"])
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """sizeof / offsetof of every struct of include/aid_hip.h as gcc lays it out == the ctypes mirror in _lib.py."""
+    import ctypes, subprocess
+    structs = {"AidGemmProblem": _lib.AidGemmProblem, "AidAttnArgs": _lib.AidAttnArgs,
+               "AidProcessorArgs": _lib.AidProcessorArgs, "AidProfileEntry": _lib.AidProfileEntry}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "aid_hip.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(out[name]) == ctypes.sizeof(cls), name
+        for fname, _ in cls._fields_:
+            assert int(out[f"{name}.{fname}"]) == getattr(cls, fname).offset, f"{name}.{fname}"

@@ -451,6 +451,84 @@ def test_every_bench_layer_at_full_size_vs_oracle(layer, cross):
 
 
 # ------------------------------------------------------------------------------------------------
+# the step either side of the call: LayerNorm in front, residual add behind
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("rows,c", [(1000, 320), (77, 640), (4097, 1280), (5, 2048), (3, 8), (14 * 1024, 1280)])
+def test_layernorm_vs_oracle(dtype, rows, c):
+    g = torch.Generator().manual_seed(rows + c)
+    x = (torch.randn(rows, c, generator=g) * 3.0 + 1.5).to(dtype)
+    gamma = (1.0 + 0.2 * torch.randn(c, generator=g)).to(dtype)
+    beta = (0.1 * torch.randn(c, generator=g)).to(dtype)
+    y = ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), eps=1e-5)
+    assert rel_l2(to_np64(y), O.layer_norm(to_np64(x), to_np64(gamma), to_np64(beta), 1e-5)) < TOL_GEMM[dtype]
+    y0 = ops.layernorm(x.to(DEV), None, None, eps=1e-5)
+    assert rel_l2(to_np64(y0), O.layer_norm(to_np64(x), None, None, 1e-5)) < TOL_GEMM[dtype]
+    with pytest.raises(RuntimeError, match="shape"):
+        ops.layernorm(torch.zeros(4, 4104, device=DEV, dtype=dtype))            # wider than 2048 channels
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("mnk", [(14336, 1280, 1280), (3000, 640, 320), (257, 324, 72), (1, 8, 8)])
+def test_gemm_residual_equals_the_separate_add(dtype, mnk):
+    """The residual goes in after the rounding of the projection, so the fused epilogue is the reference's
+    ``attn_output + hidden_states`` bit for bit (both GEMM engines and the ragged-k kernel)."""
+    m, n, k = mnk
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn(m, k, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype).to(DEV)
+    bias = torch.randn(n, generator=g).to(dtype).to(DEV)
+    res = torch.randn(m, n, generator=g).to(dtype).to(DEV)
+    assert torch.equal(ops.linear(a, w, bias, residual=res), ops.linear(a, w, bias) + res)
+    assert torch.equal(ops.linear(a, w, None, residual=res), ops.linear(a, w) + res)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("kind", ["outer", "inner", "plain"])
+@pytest.mark.parametrize("cross", [False, True], ids=["self", "cross"])
+def test_fused_sublayer_equals_norm_call_add(dtype, kind, cross):
+    n, s, heads, d, l, cc = 5, 200, 2, 64, 77, 96
+    c = heads * d
+    g = torch.Generator().manual_seed(77 + int(cross))
+    attn = aid_amd.AttnShim(c, heads, cc if cross else None, dtype=dtype, device=DEV)
+    norm = torch.nn.LayerNorm(c, eps=1e-5).to(DEV, dtype)
+    with torch.no_grad():
+        norm.weight.copy_((1.0 + 0.2 * torch.randn(c, generator=g)).to(dtype))
+        norm.bias.copy_((0.1 * torch.randn(c, generator=g)).to(dtype))
+    h = (torch.randn(2 * n, s, c, generator=g) * 2.0 + 0.5).to(dtype).to(DEV)
+    ctx = torch.randn(2 * n, l, cc, generator=g).to(dtype).to(DEV) if cross else None
+    if kind == "plain":
+        proc = aid_amd.HipAttnProcessor()
+    else:
+        cls = aid_amd.OuterInterpolatedAttnProcessor if kind == "outer" else aid_amd.InnerInterpolatedAttnProcessor
+        proc = cls(size=n, is_fused=True, alpha=3, beta=3)
+        proc.plain_tail = n
+    fused = proc.fused_sublayer(attn, norm, h, ctx)
+    xn = ops.layernorm(h, norm.weight, norm.bias, norm.eps)
+    steps = h + proc(attn, xn, encoder_hidden_states=ctx)                    # the three steps on the same kernels
+    assert torch.equal(fused, steps)
+    # against the oracle: h + attention(LayerNorm(h)) for the AID half and one rider frame
+    w = O.AttnWeights(*(to_np64(t) for t in (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
+                                              attn.to_out[0].weight, attn.to_out[0].bias)), heads)
+    hn = O.layer_norm(to_np64(h), to_np64(norm.weight), to_np64(norm.bias), norm.eps)
+    cn = None if ctx is None else to_np64(ctx)
+    if kind == "plain":
+        ref = to_np64(h[:3]) + O.plain_attention(hn[:3], None if cn is None else cn[:3], w)
+        assert rel_l2(to_np64(fused[:3]), ref) < TOL[dtype]
+    else:
+        coef = to_np64(proc.coef.to(dtype))
+        fn = O.outer_attention if kind == "outer" else O.inner_attention
+        ref = to_np64(h[:n]) + fn(hn[:n], None if cn is None else cn[:n], w, coef, True)
+        assert rel_l2(to_np64(fused[:n]), ref) < TOL[dtype]
+        refp = to_np64(h[n:n + 1]) + O.plain_attention(hn[n:n + 1], None if cn is None else cn[n:n + 1], w)
+        assert rel_l2(to_np64(fused[n:n + 1]), refp) < TOL[dtype]
+        # a foreign wrapped processor cannot be fused: the three steps run instead
+        proc.deactivate()
+        proc.original_attn = lambda a_, x_, e_=None, m_=None, t_=None: aid_amd.HipAttnProcessor()(a_, x_, e_)
+        assert torch.equal(proc.fused_sublayer(attn, norm, h, ctx), h + aid_amd.HipAttnProcessor()(attn, norm(h), ctx))
+
+
+# ------------------------------------------------------------------------------------------------
 # batched classifier-free guidance: [cond frames ; uncond frames] in ONE call (plain rider frames)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
