@@ -159,6 +159,10 @@ class AttnStackUNet(nn.Module):
         self.names = names
         self.layers = nn.ModuleList(mods)
         self.shapes = shapes
+        # the LayerNorm in front of every attention layer (BasicTransformerBlock.norm1 / norm2), used by the
+        # ``sublayers`` modes of forward()
+        self.norms = nn.ModuleList([nn.LayerNorm(c, eps=1e-5).to(device=device, dtype=dtype) for (_, c, _, _) in shapes])
+        self.sublayers = "off"
         # weights ~ N(0, 1/fan_in), bias ~ N(0, .01); generated on the target device
         gdev = self.layers[0].to_q.weight.device
         g = torch.Generator(device=gdev).manual_seed(seed)
@@ -169,6 +173,9 @@ class AttnStackUNet(nn.Module):
                     lin.weight.copy_(w.to(lin.weight.dtype))
                 m.to_out[0].bias.copy_((0.01 * torch.randn(m.to_out[0].bias.shape, generator=g, device=gdev))
                                        .to(m.to_out[0].bias.dtype))
+            for nrm in self.norms:
+                nrm.weight.copy_((1.0 + 0.1 * torch.randn(nrm.weight.shape, generator=g, device=gdev)).to(nrm.weight.dtype))
+                nrm.bias.copy_((0.05 * torch.randn(nrm.bias.shape, generator=g, device=gdev)).to(nrm.bias.dtype))
 
     @property
     def attn_processors(self) -> Dict[str, object]:
@@ -192,9 +199,21 @@ class AttnStackUNet(nn.Module):
         chained through the residual stream because the norms / convs / MLPs that
         sit between them in the real UNet are not part of this path."""
         outs: Dict[Tuple[int, int], torch.Tensor] = {}
-        for m, (s, c, h, is_cross) in zip(self.layers, self.shapes):
-            outs[(s, c)] = m(xs[(s, c)], encoder_hidden_states if is_cross else None)
-        return outs
+        if self.sublayers == "off":
+            for m, (s, c, h, is_cross) in zip(self.layers, self.shapes):
+                outs[(s, c)] = m(xs[(s, c)], encoder_hidden_states if is_cross else None)
+            return outs
+        # ``sublayers``: the residual stream of every resolution level runs through  h = h + attn(norm(h))  (what the
+        # transformer block does around attn1 / attn2; SURVEY.md §8f.2) — "steps": torch LayerNorm, processor call,
+        # torch add; "fused": one library call per layer (processors' fused_sublayer)
+        hs = dict(xs)
+        for m, nrm, (s, c, h, is_cross) in zip(self.layers, self.norms, self.shapes):
+            ctx = encoder_hidden_states if is_cross else None
+            if self.sublayers == "fused":
+                hs[(s, c)] = m.processor.fused_sublayer(m, nrm, hs[(s, c)], ctx)
+            else:
+                hs[(s, c)] = hs[(s, c)] + m(nrm(hs[(s, c)]), ctx)
+        return hs
 
     def level_shapes(self) -> List[Tuple[int, int]]:
         seen: List[Tuple[int, int]] = []

@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--guide-prompt", default="auto", choices=["auto", "on", "off"],
                     help="PAID: interior frames share the guide prompt's text context (3 distinct contexts); "
                          "auto = on for sdxl (BASELINE configs[2]), off for sd15 (configs[1]: per-frame embeddings)")
+    ap.add_argument("--sublayers", default="off", choices=["off", "steps", "fused"],
+                    help="widened workload (SURVEY.md 8f.2): every attention call with the LayerNorm in front of it and the "
+                         "residual add behind it, as three steps (torch LayerNorm / call / torch add) or as ONE library call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -187,6 +190,7 @@ def main():
     steps = args.steps
 
     unet = aid_amd.AttnStackUNet(model, dtype=dtype, device=device)
+    unet.sublayers = args.sublayers
     coef = aid_amd.generate_beta_tensor(n_total, steps, steps)
     coef[0], coef[-1] = 0, 1
     guided = args.guide_prompt == "on" or (args.guide_prompt == "auto" and model == "sdxl")
@@ -255,6 +259,9 @@ def main():
                                 else "cond + uncond (CFG) batched in one UNet call [cond ; uncond]"),
             "contexts": ("PAID guide prompt: interior frames share one text context (3 distinct per pass), keys/values "
                          "projected once per distinct context" if guided else "one text context per frame"),
+            "sublayers": {"off": "attention calls only (the BASELINE metric)",
+                          "steps": "LayerNorm + call + residual add per layer, three steps (torch LayerNorm / add)",
+                          "fused": "LayerNorm + call + residual add per layer in one library call"}[args.sublayers],
             "coef": f"BetaPPF(alpha=beta={steps})", "hipgraph": not args.no_graph,
             "parallelism": f"frame-shard x{world} (replicated end points, no per-layer collective)",
         },
