@@ -9,7 +9,7 @@ Layout:  csrc/ (HIP kernels + C ABI, built to libaid_hip.so)  ·  _lib.py (ctype
 ops.py (tensor-level entry points)  ·  processors.py (the reference's AttnProcessor classes)  ·
 interp.py (coefficients, slerp / lerp initialisation)  ·  attn_shim.py (diffusers stand-ins)  ·
 dist.py (frame sharding over RCCL)  ·  loop.py (denoising-loop harness)  ·  sequence.py (batch assembly of
-interpolate_single / N-frame interpolate).
+interpolate_single / N-frame interpolate)  ·  prior.py (Beta-prior exploration of the coefficient path).
 """
 from .interp import generate_beta_tensor, linear_interpolation, slerp, spherical_interpolation
 from .processors import (HipAttnProcessor, InnerInterpolatedAttnProcessor, InnerInterpolatedIPAttnProcessor,
@@ -17,7 +17,7 @@ from .processors import (HipAttnProcessor, InnerInterpolatedAttnProcessor, Inner
                          OuterInterpolatedIPAttnProcessor, ScaleControlIPAttnProcessor, activate_aid,
                          deactivate_aid, load_aid)
 from .attn_shim import AttnShim, AttnStackUNet, IPAdapterShim
-from . import ops, _lib, sequence, loop, dist
+from . import ops, _lib, sequence, loop, dist, prior
 
 __all__ = [
     "generate_beta_tensor", "linear_interpolation", "slerp", "spherical_interpolation",

@@ -162,3 +162,23 @@ def kat_inputs(cross: bool) -> Dict[str, np.ndarray]:
 def load_fixture(name: str) -> Dict[str, np.ndarray]:
     with np.load(os.path.join(HERE, name)) as z:
         return {k: z[k] for k in z.files}
+
+
+# ---- Beta-prior exploration (prior.py:35-340): deterministic stand-ins for the renderer and the CLIP features -----------
+def prior_feature(t: float) -> np.ndarray:
+    """Feature of the frame at coefficient t: a fixed curve on the unit sphere of R^16 with non-uniform speed, so the
+    perceptual distances between equally spaced t differ (what the exploration is there to even out)."""
+    rs = np.random.RandomState(31)
+    a, b, c = rs.randn(16), rs.randn(16), rs.randn(16)
+    s = t * t * (3 - 2 * t) ** 2 / 1.0                      # monotone warp of [0, 1]
+    v = (1 - s) * a + s * b + 0.6 * np.sin(np.pi * t) * c
+    return (v / np.linalg.norm(v)).astype(np.float32)
+
+
+PRIOR_RUNS = [dict(exploration_size=8, init_alpha=3, init_beta=3, uniform=False),
+              dict(exploration_size=12, init_alpha=3, init_beta=3, uniform=False),
+              dict(exploration_size=9, init_alpha=2, init_beta=5, uniform=False),
+              dict(exploration_size=8, init_alpha=3, init_beta=3, uniform=True)]
+PRIOR_FITS = [([0.0, 0.5, 1.0], [0.2, 0.5]), ([0.0, 0.3, 0.5, 0.8, 1.0], [0.1, 0.25, 0.3, 0.05]),
+              ([0.0, 0.2, 0.35, 0.5, 0.7, 0.9, 1.0], [0.05, 0.07, 0.2, 0.3, 0.1, 0.02])]
+PRIOR_UNIFORM = [([0.1, 0.2, 0.05, 0.3, 0.15, 0.2, 0.1, 0.05], 5), ([0.5, 0.1, 0.1, 0.1, 0.1, 0.1], 3), ([0.2] * 15, 7)]

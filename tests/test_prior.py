@@ -1,0 +1,55 @@
+"""Beta-prior exploration against fixtures produced by the reference's own BetaPriorPipeline methods
+(tests/golden/make_prior_goldens.py; renderer and CLIP features replaced by the deterministic stand-ins of cases.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+import aid_amd
+from aid_amd import prior as P
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prior_goldens.npz"))
+
+
+def _generator(calls):
+    def generate(ts):
+        calls.append(list(ts))
+        pts = [0.0] + [float(t) for t in ts] + [1.0]
+        return pts, [torch.from_numpy(C.prior_feature(t))[None] for t in pts]
+    return generate
+
+
+@pytest.mark.parametrize("r", range(len(C.PRIOR_RUNS)))
+def test_exploration_follows_the_reference(r):
+    calls = []
+    ex = P.BetaPriorExplorer(_generator(calls))
+    frames, features, ds, xs, alpha, beta = ex.explore(**C.PRIOR_RUNS[r])
+    np.testing.assert_allclose(xs, G[f"run{r}_xs"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose([float(d) for d in ds], G[f"run{r}_ds"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose([alpha, beta], G[f"run{r}_ab"], rtol=1e-6)
+    assert frames == list(xs)                                        # the stand-in "image" of a frame is its coefficient
+    assert len(calls) == len(xs) - 2 and all(len(c) == 1 for c in calls)     # one batch-3 run per point, like the reference
+    assert P.extract_uniform_points_plus(features, 5) == G[f"run{r}_path5"].tolist()
+    assert P.extract_uniform_points(ds, 5) == G[f"run{r}_uniform5"].tolist()
+
+
+def test_fit_and_uniform_pick_known_answers():
+    for i, (xs, ds) in enumerate(C.PRIOR_FITS):
+        np.testing.assert_allclose(P.update_alpha_beta(xs, ds), G[f"fit{i}"], rtol=1e-6)
+    for i, (ds, n) in enumerate(C.PRIOR_UNIFORM):
+        assert P.extract_uniform_points(ds, n) == G[f"uniform{i}"].tolist()
+
+
+def test_batched_exploration_fills_several_gaps_per_run():
+    calls = []
+    ex = P.BetaPriorExplorer(_generator(calls))
+    frames, features, ds, xs, alpha, beta = ex.explore(exploration_size=12, batch=3)
+    assert len(xs) == 12 and xs == sorted(xs) and xs[0] == 0.0 and xs[-1] == 1.0 and len(set(xs)) == 12
+    assert [len(c) for c in calls] == [1, 2, 3, 3, 1] and all(c == sorted(c) for c in calls)   # 9 single runs in the reference
+    assert len(ds) == 11 and len(frames) == 12 and frames == xs
+    np.testing.assert_allclose([float(d) for d in ds],
+                               [float(P.clip_distance(features[i], features[i + 1])) for i in range(11)], atol=1e-7)
+    out = ex.generate_interpolation(interpolation_size=5, exploration_size=10, batch=2)
+    assert len(out) == 5 and out[0] == 0.0 and out[-1] == 1.0 and out == sorted(out)
