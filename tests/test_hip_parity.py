@@ -619,6 +619,40 @@ def test_loop_with_shared_contexts_matches_repeated_contexts():
                 assert torch.equal(a[k], b[k])
 
 
+def test_prior_exploration_renders_candidate_batches_on_the_hip_stack():
+    """the Beta-prior exploration asks for several candidate coefficients per round; each round is ONE
+    N-frame AID call sequence over [0, *ts, 1] with that (arbitrary, non-Beta) coefficient vector."""
+    from aid_amd.prior import BetaPriorExplorer
+    dtype = torch.float16
+    unet = aid_amd.AttnStackUNet("sd15", dtype=dtype, device=DEV, scale_down=16)
+    g = torch.Generator().manual_seed(8)
+    ends = {lv: torch.randn(2, lv[0], lv[1], generator=g) for lv in unet.level_shapes()}
+    ctx_ends = torch.randn(2, unet.text_len, unet.cross_dim, generator=g)
+    unc = torch.randn(1, unet.text_len, unet.cross_dim, generator=g)
+    sizes = []
+
+    def generate(ts):
+        coef = torch.tensor([0.0] + [float(t) for t in ts] + [1.0])
+        n = coef.numel()
+        sizes.append(n)
+        install_sequence_processors(unet, n, early="fused_outer", coef=coef)
+        xs = {lv: torch.stack([aid_amd.slerp(e[0:1], e[1:2], float(c))[0] for c in coef]).to(dtype).to(DEV) for lv, e in ends.items()}
+        cond = torch.stack([torch.lerp(ctx_ends[0], ctx_ends[1], float(c)) for c in coef]).to(dtype).to(DEV)
+        loop = AidDenoiseLoop(unet, xs, cond, unc.expand(n, -1, -1).to(dtype).to(DEV).contiguous(), num_inference_steps=2,
+                              use_graphs=False, batched_cfg=True)
+        out = loop.step(0)[unet.level_shapes()[0]].float()
+        assert torch.isfinite(out).all()
+        return [float(c) for c in coef], [out[i].mean(dim=0, keepdim=True).cpu() for i in range(n)]
+
+    runs = []
+    for _ in range(2):
+        sizes.clear()
+        frames, features, ds, xs, alpha, beta = BetaPriorExplorer(generate).explore(exploration_size=8, batch=3)
+        runs.append((xs, [float(d) for d in ds], float(alpha), float(beta)))
+        assert sizes == [3, 4, 5] and len(xs) == 8 and xs == sorted(xs) and np.allclose(frames, xs, atol=1e-6)
+    assert runs[0] == runs[1]                                    # the HIP path is deterministic, so is the search
+
+
 # ------------------------------------------------------------------------------------------------
 # randomized shapes (seeded): every mode, ragged S / L, shard-style end points, both dtypes
 # ------------------------------------------------------------------------------------------------
