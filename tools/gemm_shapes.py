@@ -11,6 +11,8 @@ shapes = [(300, 200, 64), (256, 256, 128), (1000, 520, 1280), (8192, 8192, 8192)
           (57344, 640, 640), (57344, 960, 320), (14336, 640, 640), (3584, 1280, 1280)]
 if os.environ.get("AID_SHAPES") == "short":
     shapes = [(70000, 520, 128), (8192, 8192, 8192), (4096, 4096, 4096), (14336, 3840, 1280), (14336, 1280, 1280)]
+if os.environ.get("AID_SHAPES") == "small":
+    shapes = [(57344, 320, 320), (14336, 640, 640), (3584, 1280, 1280), (3584, 3840, 1280), (14336, 1920, 640), (1078, 1280, 2048)]
 if os.environ.get("AID_SHAPES") == "ksweep":
     shapes = [(4096, 4096, k) for k in (128, 640, 1280, 2560, 5120)] + [(14336, 1280, 1280), (14336, 3840, 1280)]
 dt = torch.float16 if (len(sys.argv) > 1 and sys.argv[1] == "f16") else torch.bfloat16
