@@ -7,14 +7,18 @@
 // consecutive n of one output row.  The 1-D grid is remapped XCD-aware so the blocks that share an A
 // row panel run on one XCD / one L2.
 //
-//  * aid_gemm_nt_pipe_kernel — main path (every k % BK == 0: all SD1.5 / SDXL projection shapes).
-//    Operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no
-//    VGPR round trip, no ds_write pass) into an NS-deep ring; NS-1 tiles stay in flight across the
-//    (raw) workgroup barrier with a counted s_waitcnt vmcnt.  LDS-DMA writes lane-linear images, so
-//    rows are unpadded and the bank-conflict-free layout comes from an XOR swizzle applied to the
-//    per-lane SOURCE address and again on the fragment read.  Fragment reads run one k-step ahead of
-//    the MFMAs.  The C tile is staged through LDS (re-using the ring) and written as full
-//    16-B-per-lane row segments.
+//  * aid_gemm_nt_pipe_kernel — lock-step engine, 128 x 128 x 64 tiles, 2 workgroups / CU (every k % 64 == 0 shape
+//    can run on it).  Operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction,
+//    no VGPR round trip, no ds_write pass) into a 2-deep ring with a (raw) workgroup barrier and a counted
+//    s_waitcnt vmcnt per K tile.  LDS-DMA writes lane-linear images, so rows are unpadded and the
+//    bank-conflict-free layout comes from an XOR swizzle applied to the per-lane SOURCE address and again on the
+//    fragment read.  Fragment reads run one k-step ahead of the MFMAs.  The C tile is staged through LDS (re-using
+//    the ring) and written as full 16-B-per-lane row segments; an optional residual is added there, after the
+//    rounding, like the transformer block's separate add.
+//  * aid_gemm_nt_pp_kernel — ping-pong engine, 256 x 256 x 64 tiles, 1 workgroup / CU: two groups of four waves run
+//    one barrier apart so one group's MFMAs cover the other group's LDS reads (struct PingPong); the ragged last
+//    round of big tiles is cut into 128 x 128 tiles that the lock-step engine computes inside the same launch.
+//    launch_gemm() picks the engine per launch with a small cost model (long K loops + many tiles -> ping-pong).
 //  * aid_gemm_nt_kernel — edge path for ragged k (tests, odd context widths): 128x128 tile,
 //    register-staged, fully guarded loads, padded LDS rows.
 #include "aid_common.hpp"
