@@ -17,7 +17,7 @@ coefficients from rank 0 and ``all_gather`` of the final latents of the owned fr
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Tuple
 
 import torch
 import torch.distributed as dist

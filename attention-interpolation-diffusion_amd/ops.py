@@ -7,7 +7,7 @@ synchronise.  Tensors must live on a HIP device and be fp16 / bf16 — anything 
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 

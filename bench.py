@@ -23,7 +23,6 @@ Rank 0 prints ONE JSON line (see the task contract); N=1 additionally measures
                  sample and extrapolated to the same 50-step unit.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
