@@ -178,3 +178,11 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert int(out[name]) == ctypes.sizeof(cls), name
         for fname, _ in cls._fields_:
             assert int(out[f"{name}.{fname}"]) == getattr(cls, fname).offset, f"{name}.{fname}"
+
+
+def test_integration_doc_stub_matches_the_header():
+    """The ctypes stub a maintainer would copy from INTEGRATION.md lists the AidProcessorArgs fields of the header, in order."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class AidProcessorArgs(C.Structure)"):doc.index("lib.aid_processor_workspace_bytes.restype")]
+    names = re.findall(r'\("(\w+)", C\.', stub)
+    assert names == [f for f, _ in _lib.AidProcessorArgs._fields_]
