@@ -12,10 +12,10 @@ dist.py (frame sharding over RCCL)  ·  loop.py (denoising-loop harness)  ·  se
 interpolate_single / N-frame interpolate)  ·  prior.py (Beta-prior exploration of the coefficient path).
 """
 from .interp import generate_beta_tensor, linear_interpolation, slerp, spherical_interpolation
-from .processors import (HipAttnProcessor, InnerInterpolatedAttnProcessor, InnerInterpolatedIPAttnProcessor,
-                         InterpolatedAttnProcessor, OuterInterpolatedAttnProcessor,
+from .processors import (HipAttnProcessor, HipIPAdapterAttnProcessor, InnerInterpolatedAttnProcessor,
+                         InnerInterpolatedIPAttnProcessor, InterpolatedAttnProcessor, OuterInterpolatedAttnProcessor,
                          OuterInterpolatedIPAttnProcessor, ScaleControlIPAttnProcessor, activate_aid,
-                         deactivate_aid, load_aid)
+                         deactivate_aid, load_aid, load_aid_ip_adapter)
 from .attn_shim import AttnShim, AttnStackUNet, IPAdapterShim
 from . import ops, _lib, sequence, loop, dist, prior
 
@@ -23,7 +23,7 @@ __all__ = [
     "generate_beta_tensor", "linear_interpolation", "slerp", "spherical_interpolation",
     "InterpolatedAttnProcessor", "OuterInterpolatedAttnProcessor", "InnerInterpolatedAttnProcessor",
     "OuterInterpolatedIPAttnProcessor", "InnerInterpolatedIPAttnProcessor", "ScaleControlIPAttnProcessor",
-    "HipAttnProcessor", "load_aid", "activate_aid", "deactivate_aid",
+    "HipAttnProcessor", "HipIPAdapterAttnProcessor", "load_aid", "load_aid_ip_adapter", "activate_aid", "deactivate_aid",
     "AttnShim", "AttnStackUNet", "IPAdapterShim", "ops",
 ]
 __version__ = "0.1.0"

@@ -15,10 +15,11 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AID_LIB_PATH") or os.path.join(PKG_DIR, "libaid_hip.so")   # override: development A/B builds
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
-AID_ABI_VERSION = 2
+AID_ABI_VERSION = 3
 DTYPE_F16, DTYPE_BF16 = 0, 1
 MODE_PLAIN, MODE_INNER, MODE_OUTER = 0, 1, 2
-GEMM_MAX_PROBLEMS = 4
+GEMM_MAX_PROBLEMS = 6
+IP_NONE, IP_SAME, IP_PLAIN = 0, 1, 2
 
 # every symbol include/aid_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -52,6 +53,7 @@ class AidAttnArgs(C.Structure):
         ("accumulate", C.c_int32), ("dtype", C.c_int32),
         ("softmax_scale", C.c_float), ("out_scale", C.c_float),
         ("n_plain", C.c_int32), ("q_prescaled", C.c_int32),
+        ("seg_executed", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -66,11 +68,16 @@ class AidProcessorArgs(C.Structure):
         ("ctx_map", C.c_void_p),
         ("n_plain", C.c_int32), ("ln_eps", C.c_float),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("residual", C.c_void_p),
+        ("ip", C.c_void_p), ("wk_ip", C.c_void_p), ("wv_ip", C.c_void_p), ("ip_map", C.c_void_p),
+        ("ip_frame_scale", C.c_void_p), ("ip_stride", C.c_int64),
+        ("n_ip", C.c_int32), ("t_ip", C.c_int32), ("ip_mode", C.c_int32), ("ip_scale", C.c_float),
+        ("ip_begin", C.c_int32), ("ip_end", C.c_int32), ("seg_executed", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
 class AidProfileEntry(C.Structure):
-    _fields_ = [("kernel", C.c_char * 64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+    _fields_ = [("kernel", C.c_char * 64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double),
+                ("flops_executed", C.c_double)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -93,7 +93,9 @@ class AttnShim(nn.Module):
 
 class IPAdapterShim(nn.Module):
     """The state the IP processors share with diffusers' IPAdapterAttnProcessor2_0
-    (interpolation.py:70-74): to_k_ip / to_v_ip ModuleLists, scale list, num_tokens."""
+    (interpolation.py:70-74): to_k_ip / to_v_ip ModuleLists, scale list, num_tokens.  A weight holder only
+    (``weights_only``): a de-activated IP processor that wraps it runs ``HipIPAdapterAttnProcessor`` on these weights."""
+    weights_only = True
 
     def __init__(self, hidden_size: int, cross_attention_dim: int, num_tokens: int = 4,
                  scale: float = 1.0, dtype=torch.float32, device=None):
@@ -176,6 +178,25 @@ class AttnStackUNet(nn.Module):
             for nrm in self.norms:
                 nrm.weight.copy_((1.0 + 0.1 * torch.randn(nrm.weight.shape, generator=g, device=gdev)).to(nrm.weight.dtype))
                 nrm.bias.copy_((0.05 * torch.randn(nrm.bias.shape, generator=g, device=gdev)).to(nrm.bias.dtype))
+
+    def load_ip_adapter(self, num_tokens: int = 4, scale: float = 1.0, seed: int = 7):
+        """Stand-in for diffusers' ``load_ip_adapter`` on this stack (third-party; the reference calls it first,
+        pipeline_interpolated_sd.py:986-992): every text cross-attention layer (attn2) gets an IP-Adapter processor with
+        synthetic ``to_k_ip`` / ``to_v_ip`` weights ~ N(0, 1/fan_in); self-attention layers keep theirs.  The cross layers
+        are then fed ``encoder_hidden_states = (text, [image_embeds])``."""
+        from .processors import HipAttnProcessor, HipIPAdapterAttnProcessor
+        dev, dt = self.layers[0].to_q.weight.device, self.layers[0].to_q.weight.dtype
+        g = torch.Generator(device=dev).manual_seed(seed)
+        with torch.no_grad():
+            for m, (s, c, h, is_cross) in zip(self.layers, self.shapes):
+                if not is_cross:
+                    if m.processor is None:
+                        m.processor = HipAttnProcessor()
+                    continue
+                p = HipIPAdapterAttnProcessor(c, self.cross_dim, num_tokens=(num_tokens,), scale=scale, dtype=dt, device=dev)
+                for lin in (p.to_k_ip[0], p.to_v_ip[0]):
+                    lin.weight.copy_((torch.randn(lin.weight.shape, generator=g, device=dev) / lin.weight.shape[1] ** 0.5).to(dt))
+                m.processor = p
 
     @property
     def attn_processors(self) -> Dict[str, object]:

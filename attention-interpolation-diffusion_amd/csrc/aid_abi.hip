@@ -24,7 +24,7 @@ int fail_hip(hipError_t e, const char* where) {
 struct ProfRec {
     hipEvent_t t0, t1;
     char name[64];
-    double flops, bytes;
+    double flops, bytes, flops_exec;
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -32,7 +32,8 @@ std::vector<ProfRec> g_prof;
 struct ProfScope {          // records an event pair around one launch when profiling is on
     hipStream_t stream;
     bool on;
-    ProfScope(hipStream_t s, const char* name, double flops, double bytes) : stream(s), on(g_prof_on) {
+    ProfScope(hipStream_t s, const char* name, double flops, double bytes, double flops_exec = -1.0)
+        : stream(s), on(g_prof_on) {
         if (!on) return;
         ProfRec r;
         (void)hipEventCreate(&r.t0);
@@ -40,8 +41,12 @@ struct ProfScope {          // records an event pair around one launch when prof
         snprintf(r.name, sizeof(r.name), "%s", name);
         r.flops = flops;
         r.bytes = bytes;
+        r.flops_exec = flops_exec < 0.0 ? flops : flops_exec;
         (void)hipEventRecord(r.t0, stream);
         g_prof.push_back(r);
+    }
+    void rename(const char* name) {      // the kernel symbol is known only after the launcher picked an engine
+        if (on) snprintf(g_prof.back().name, sizeof(g_prof.back().name), "%s", name);
     }
     ~ProfScope() {
         if (on) (void)hipEventRecord(g_prof.back().t1, stream);
@@ -63,8 +68,8 @@ int check_problem(const AidGemmProblem& q) {
 }
 
 struct Carve {
-    size_t q, k, vt, o, k2, vt2, xn, total;
-    int lp;
+    size_t q, k, vt, o, k2, vt2, xn, kip, vtip, total;
+    int lp, tp;
 };
 
 Carve carve(const AidProcessorArgs& a) {
@@ -85,6 +90,12 @@ Carve carve(const AidProcessorArgs& a) {
     }
     c.xn = off;
     if (a.ln_eps > 0.f) off += align_up((size_t)a.n_frames * a.s * a.c * es, 256);     // LayerNorm(x)
+    c.kip = c.vtip = off;
+    c.tp = round_up(a.ip ? a.t_ip : 0, 8);
+    if (a.ip) {                                           // image keys / values^T of the IP-Adapter branch
+        c.kip = off;  off += align_up((size_t)a.n_ip * a.t_ip * a.c * es, 256);
+        c.vtip = off; off += align_up((size_t)a.n_ip * a.c * c.tp * es, 256);
+    }
     c.total = off;
     return c;
 }
@@ -105,6 +116,17 @@ int check_processor(const AidProcessorArgs& a) {
         return AID_ERR_ARG;
     }
     if (a.mode != AID_MODE_PLAIN && (a.begin < 0 || a.begin >= nctx || a.end < 0 || a.end >= nctx)) return AID_ERR_ARG;
+    if (a.ip) {
+        if (!a.ctx || !a.wk_ip || !a.wv_ip || a.n_ip < 1 || a.t_ip < 1) return AID_ERR_ARG;
+        if (a.ip_mode != AID_IP_SAME && a.ip_mode != AID_IP_PLAIN) return AID_ERR_ARG;
+        if (a.ip_mode == AID_IP_SAME && (a.mode != AID_MODE_OUTER || a.ip_begin < 0 || a.ip_begin >= a.n_ip ||
+                                         a.ip_end < 0 || a.ip_end >= a.n_ip)) return AID_ERR_ARG;
+        if (!a.ip_map && a.n_ip < a.n_frames) return AID_ERR_ARG;
+        if (a.ip_stride % 8 || a.ip_stride < (int64_t)a.t_ip * a.cc) return AID_ERR_SHAPE;
+        if (!aligned16(a.ip) || !aligned16(a.wk_ip) || !aligned16(a.wv_ip)) return AID_ERR_SHAPE;
+    } else if (a.ip_mode != AID_IP_NONE) {
+        return AID_ERR_ARG;
+    }
     if (!(a.ln_eps >= 0.f)) return AID_ERR_ARG;
     if (a.ln_eps > 0.f) {
         if (!aid::layernorm_width_supported(a.c)) return AID_ERR_SHAPE;
@@ -167,6 +189,7 @@ int aid_profile_end(AidProfileEntry* entries, int max_entries) {
             entries[n].ms = ms;
             entries[n].flops = r.flops;
             entries[n].bytes = r.bytes;
+            entries[n].flops_executed = r.flops_exec;
             ++n;
         }
         (void)hipEventDestroy(r.t0);
@@ -206,9 +229,15 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
     }
     hipError_t e;
     {
-        ProfScope ps(static_cast<hipStream_t>(stream), dtype == AID_DTYPE_F16 ? "aid_gemm_nt<f16>" : "aid_gemm_nt<bf16>",
-                     flops, bytes);
+        ProfScope ps(static_cast<hipStream_t>(stream), "aid_gemm_nt", flops, bytes);
         e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream), &g_gemm_variant);
+        // profile entries carry the kernel SYMBOL that ran, so they line up with rocprofv3's per-kernel rows
+        char nm[64];
+        const char* sym = !strncmp(g_gemm_variant, "pingpong", 8) ? "aid_gemm_nt_pp_kernel"
+                          : !strcmp(g_gemm_variant, "edge")      ? "aid_gemm_nt_kernel"
+                                                                 : "aid_gemm_nt_pipe_kernel";
+        snprintf(nm, sizeof(nm), "%s<%s>", sym, dtype == AID_DTYPE_F16 ? "f16" : "bf16");
+        ps.rename(nm);
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_gemm_nt");
 }
@@ -247,12 +276,14 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     // pure outer 2, fused outer 3
     const int segs = a.mode == AID_MODE_PLAIN ? 1 : (a.mode == AID_MODE_INNER ? 1 : 2) + (a.fused ? 1 : 0);
     const double c = (double)a.heads * a.d;
-    const double flops = 4.0 * a.s * (double)a.l * c * ((double)segs * (a.n_frames - a.n_plain) + a.n_plain);
+    const double per_seg = 4.0 * a.s * (double)a.l * c;
+    const double flops = per_seg * ((double)segs * (a.n_frames - a.n_plain) + a.n_plain);
+    const double flops_exec = a.seg_executed > 0 ? per_seg * a.seg_executed : flops;
     const double bytes = 2.0 * (2.0 * a.n_frames * a.s * c + 2.0 * a.n_kv * a.l * c);
     hipError_t e;
     {
         const char* nm = aid::attn_variant_name(a);
-        ProfScope ps(static_cast<hipStream_t>(stream), nm, flops, bytes);
+        ProfScope ps(static_cast<hipStream_t>(stream), nm, flops, bytes, flops_exec);
         e = aid::attn_launch(a, static_cast<hipStream_t>(stream), &g_variant);
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
@@ -314,7 +345,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     const int d = a.c / a.heads;
 
     // 1. q, k and V^T projections in one grouped launch
-    AidGemmProblem pr[3];
+    AidGemmProblem pr[5];
     memset(pr, 0, sizeof(pr));
     pr[0].a = xin;  pr[0].b = a.wq; pr[0].c = q;
     pr[0].m = a.n_frames * a.s; pr[0].n = a.c; pr[0].k = a.c;
@@ -327,7 +358,21 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     pr[2].m = a.c; pr[2].n = l; pr[2].k = cc;
     pr[2].lda = cc; pr[2].ldb = cc; pr[2].ldc = cv.lp; pr[2].batch = nctx;
     pr[2].stride_a = 0; pr[2].stride_b = (int64_t)l * cc; pr[2].stride_c = (int64_t)a.c * cv.lp;
-    rc = aid_gemm_nt(pr, 3, a.dtype, stream);
+    int npr = 3;
+    void* kip = ws + cv.kip;
+    void* vtip = ws + cv.vtip;
+    if (a.ip) {                                               // K_ip = to_k_ip(ip rows), V_ip^T = Wv_ip * ip_row^T
+        pr[3].a = a.ip; pr[3].b = a.wk_ip; pr[3].c = kip;
+        pr[3].m = a.t_ip; pr[3].n = a.c; pr[3].k = a.cc;
+        pr[3].lda = a.cc; pr[3].ldb = a.cc; pr[3].ldc = a.c; pr[3].batch = a.n_ip;
+        pr[3].stride_a = a.ip_stride; pr[3].stride_b = 0; pr[3].stride_c = (int64_t)a.t_ip * a.c;
+        pr[4].a = a.wv_ip; pr[4].b = a.ip; pr[4].c = vtip;
+        pr[4].m = a.c; pr[4].n = a.t_ip; pr[4].k = a.cc;
+        pr[4].lda = a.cc; pr[4].ldb = a.cc; pr[4].ldc = cv.tp; pr[4].batch = a.n_ip;
+        pr[4].stride_a = 0; pr[4].stride_b = a.ip_stride; pr[4].stride_c = (int64_t)a.c * cv.tp;
+        npr = 5;
+    }
+    rc = aid_gemm_nt(pr, npr, a.dtype, stream);
     if (rc != AID_OK) return rc;
 
     // 2. interpolated attention core (INNER: interpolated K / V^T of the interior frames first)
@@ -353,8 +398,27 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     at.out_scale = 1.0f;
     at.n_plain = a.n_plain;
     at.q_prescaled = 1;
+    at.seg_executed = a.seg_executed;
     rc = aid_attn_fwd(&at, stream);
     if (rc != AID_OK) return rc;
+
+    // 2b. IP-Adapter image branch: a second (short) attention launch that accumulates into o
+    if (a.ip) {
+        AidAttnArgs ai = at;
+        ai.k = kip; ai.vt = vtip; ai.k2 = nullptr; ai.vt2 = nullptr;
+        ai.kv_map = a.ip_map; ai.n_kv = a.n_ip; ai.l = a.t_ip;
+        ai.ldk = a.c; ai.ldvt = cv.tp;
+        ai.k_fs = (int64_t)a.t_ip * a.c; ai.vt_fs = (int64_t)a.c * cv.tp;
+        ai.accumulate = 1; ai.out_scale = a.ip_scale; ai.frame_scale = a.ip_frame_scale;
+        ai.seg_executed = 0;
+        if (a.ip_mode == AID_IP_SAME) {                   // same scheme as the text keys (OUTER), image end-point rows
+            ai.begin = a.ip_begin; ai.end = a.ip_end;
+        } else {                                          // every frame with its own image keys
+            ai.mode = AID_MODE_PLAIN; ai.fused = 0; ai.coef = nullptr; ai.begin = 0; ai.end = 0; ai.n_plain = 0;
+        }
+        rc = aid_attn_fwd(&ai, stream);
+        if (rc != AID_OK) return rc;
+    }
 
     // 3. out projection + bias
     AidGemmProblem po;

@@ -540,12 +540,14 @@ template <typename T, int D, int MODE, int NW>
 static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
     const size_t smem = (size_t)(attn_prefetch(D, NW) ? 2 : 1) * (KT * (DK + 8) + DV * VLD) * sizeof(T);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice<bool> attr_set;
+    bool* done = attr_set.slot();
+    if (!done) return hipErrorInvalidDevice;
+    if (!*done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        *done = true;
     }
     const int grid = p.nqb * p.a.n_frames * p.a.heads;
     hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW>), dim3(grid), dim3(NW * 64), smem, stream, p);

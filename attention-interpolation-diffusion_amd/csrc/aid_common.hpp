@@ -89,4 +89,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return base + j;
 }
 
+// Host side: state that is per DEVICE, not per process (hipFuncSetAttribute applies to the current device only, and a
+// process may drive several GPUs).  slot() returns the current device's entry, or nullptr when there is no device.
+template <typename V>
+struct PerDevice {
+    static constexpr int MAXD = 64;
+    V v[MAXD] = {};
+    V* slot() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAXD) return nullptr;
+        return &v[d];
+    }
+};
+
 }  // namespace aid

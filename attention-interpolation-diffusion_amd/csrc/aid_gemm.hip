@@ -663,14 +663,16 @@ static int plan_tiles(GemmGroup& g, int bm, int bn) {
 }
 
 template <typename K>
-static hipError_t launch_with_smem(K kernel, size_t smem, bool* attr_set, const GemmGroup& g, int total_tiles,
+static hipError_t launch_with_smem(K kernel, size_t smem, PerDevice<bool>* attr_set, const GemmGroup& g, int total_tiles,
                                    hipStream_t stream, int threads) {
     if (total_tiles <= 0) return hipSuccess;
-    if (!*attr_set) {
+    bool* done = attr_set->slot();
+    if (!done) return hipErrorInvalidDevice;
+    if (!*done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        *attr_set = true;
+        *done = true;
     }
     hipLaunchKernelGGL(kernel, dim3(total_tiles), dim3(threads), smem, stream, g);
     return hipGetLastError();
@@ -678,21 +680,23 @@ static hipError_t launch_with_smem(K kernel, size_t smem, bool* attr_set, const 
 
 template <typename T, int BM, int BN, int BK, int NS, int WM, int WN>
 static hipError_t launch_pipe(GemmGroup& g, hipStream_t stream) {
-    static bool attr_set = false;
+    static PerDevice<bool> attr_set;
     return launch_with_smem(aid_gemm_nt_pipe_kernel<T, BM, BN, BK, NS, WM, WN>, Engine<T, BM, BN, BK, NS, WM, WN>::SMEM,
                             &attr_set, g, plan_tiles(g, BM, BN), stream, WM * WN * 64);
 }
 
-static int g_num_cu = 0;
+static PerDevice<int> g_num_cu;
 
-static int num_cu() {
-    if (g_num_cu == 0) {
+static int num_cu() {                       // CU count of the CURRENT device (cached per device)
+    int* n = g_num_cu.slot();
+    if (!n) return 0;
+    if (*n == 0) {
         int dev = 0;
         hipDeviceProp_t pr;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
-        g_num_cu = pr.multiProcessorCount;
+        *n = pr.multiProcessorCount;
     }
-    return g_num_cu;
+    return *n;
 }
 
 // Plan of the ping-pong path: n_big 256 x 256 tiles (whole CU rounds) + the ragged rest as 128 x 128 tiles.
@@ -717,14 +721,16 @@ static PpPlan plan_pp(GemmGroup& g, int ncu, int nk) {
 
 template <typename T>
 static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl) {
-    static bool attr_set = false;
+    static PerDevice<bool> attr_set;
     if (pl.tiles <= 0) return hipSuccess;
     if (plan_tiles(g, 256, 256) != pl.tiles) return hipErrorInvalidValue;      // g.tile_start must be in 256 x 256 units
-    if (!attr_set) {
+    bool* done = attr_set.slot();
+    if (!done) return hipErrorInvalidDevice;
+    if (!*done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(aid_gemm_nt_pp_kernel<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PingPong<T>::SMEM);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        *done = true;
     }
     hipLaunchKernelGGL(aid_gemm_nt_pp_kernel<T>, dim3(pl.n_big + pl.n_small), dim3(512), PingPong<T>::SMEM, stream, g,
                        pl.n_big);
@@ -744,7 +750,7 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** var
     bool k64 = true;
     for (int i = 0; i < g.n_problems; ++i) k64 = k64 && (g.p[i].k % 64 == 0);
     if (!k64) {
-        static bool s0 = false;
+        static PerDevice<bool> s0;
         if (variant) *variant = "edge";
         return launch_with_smem(aid_gemm_nt_kernel<T>, (size_t)2 * (GBM + GBN) * GLD * sizeof(T), &s0, g,
                                 plan_tiles(g, GBM, GBN), stream, GTHREADS);

@@ -87,7 +87,7 @@ def broadcast_conditioning(tensors: Dict[str, torch.Tensor], src: int = 0, group
     """Once-per-run broadcast of the conditioning (prompt embeddings, pooled embeds / time ids, image
     embeds, initial latents, coefficients) from ``src``.  Every rank passes tensors of the right shape
     and dtype; they are filled in place."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():        # also with one rank: the collective path is the same
         for name in sorted(tensors):
             t = tensors[name]
             if _needs_host_hop(t, group):          # gloo with device tensors (1-GPU development mode)
@@ -104,9 +104,11 @@ def gather_owned(local: torch.Tensor, shard: FrameShard, group=None) -> torch.Te
     (same result on every rank).  Owned counts differ by at most one, so rows are padded to the max."""
     lo, hi = shard.owned_local
     own = local[lo:hi]
-    if not (dist.is_available() and dist.is_initialized()) or shard.world_size == 1:
-        assert shard.n_owned == shard.n_frames
+    if not (dist.is_available() and dist.is_initialized()):
+        assert shard.world_size == 1 and shard.n_owned == shard.n_frames
         return own.contiguous()
+    if dist.get_world_size(group) != shard.world_size:
+        raise ValueError(f"shard was made for {shard.world_size} ranks, the process group has {dist.get_world_size(group)}")
     parts = partition_frames(shard.n_frames, shard.world_size)
     mx = max(b - a for a, b in parts)
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

@@ -89,6 +89,8 @@ class AidDenoiseLoop:
         reference's two separate calls while every GEMM sees twice the rows and the launch count halves."""
         """``ctx_index`` (frame -> row of ``cond`` / ``uncond``): the sequence shares text contexts (PAID guide
         prompt, sequence.py); ``cond`` / ``uncond`` then hold the DISTINCT contexts only."""
+        """``cond`` / ``uncond`` may be ``(text, [image_embeds])`` tuples — the ``encoder_hidden_states`` an IP-Adapter UNet
+        hands its attention layers (interpolation.py:259-266); the two passes then run as two UNet calls."""
         self.unet, self.sample, self.cond, self.uncond = unet, sample, cond, uncond
         self.batched_cfg = batched_cfg
         first = next(iter(sample.values())) if isinstance(sample, dict) else sample
@@ -96,7 +98,10 @@ class AidDenoiseLoop:
         self.ctx_index = None if ctx_index is None else [int(i) for i in ctx_index]
         if self.ctx_index is not None and len(self.ctx_index) != self.n_frames:
             raise ValueError("ctx_index needs one entry per frame")
-        if self.ctx_index is None and cond.shape[0] != self.n_frames:
+        if isinstance(cond, tuple):
+            if batched_cfg or ctx_index is not None:
+                raise ValueError("(text, [image_embeds]) contexts run as two separate passes without ctx_index")
+        elif self.ctx_index is None and cond.shape[0] != self.n_frames:
             raise ValueError("one context per frame expected (or pass ctx_index)")
         self.ctx_index2 = None
         if batched_cfg:

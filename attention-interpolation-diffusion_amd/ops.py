@@ -6,16 +6,18 @@ synchronise.  Tensors must live on a HIP device and be fp16 / bf16 — anything 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 
 from . import _lib
-from ._lib import (DTYPE_BF16, DTYPE_F16, MODE_INNER, MODE_OUTER, MODE_PLAIN, AidAttnArgs,
+from ._lib import (DTYPE_BF16, DTYPE_F16, IP_NONE, IP_PLAIN, IP_SAME, MODE_INNER, MODE_OUTER, MODE_PLAIN, AidAttnArgs,
                    AidGemmProblem, AidProcessorArgs)
 
 MODES = {"plain": MODE_PLAIN, "inner": MODE_INNER, "outer": MODE_OUTER}
+IP_MODES = {"same": IP_SAME, "plain": IP_PLAIN}
 SUPPORTED_HEAD_DIMS = (40, 64, 80, 160)
 
 
@@ -45,6 +47,40 @@ def _require_gpu(*ts: Optional[torch.Tensor]) -> torch.device:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+@contextlib.contextmanager
+def _on(dev: Optional[torch.device]):
+    """Make the tensors' device the current one for the launch: the library enqueues on the CURRENT device's stream and
+    keeps its per-kernel attributes per device, so a process that drives several GPUs (or calls with tensors of a
+    non-current device) must not launch on the wrong device's stream."""
+    if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+        yield
+    else:
+        with torch.cuda.device(dev):
+            yield
+
+
+def executed_segments(mode: str, fused: bool, coef_vals: Optional[Sequence[float]], n_frames: int,
+                      own_rows: Optional[Sequence[int]] = None, begin: int = 0, end: int = -1) -> int:
+    """(frame, key segment) passes the attention kernel really runs for one launch — the bookkeeping behind
+    ``AidProfileEntry.flops_executed`` (csrc/aid_attn.hip): a PLAIN rider (negative coefficient) and a fused END-POINT
+    frame take one pass over their own keys; a coefficient of exactly 0 / 1 drops the zero-weighted side of OUTER."""
+    if mode == "plain" or coef_vals is None:
+        return n_frames
+    own = list(range(n_frames)) if own_rows is None else list(own_rows)
+    n_rows = max(own) + 1
+    begin, end = begin % n_rows, end % n_rows
+    total = 0
+    for i in range(n_frames):
+        c = coef_vals[i]
+        if c < 0 or (fused and ((c == 0 and own[i] == begin) or (c == 1 and own[i] == end))):
+            total += 1
+        elif mode == "inner":
+            total += 2 if fused else 1
+        else:
+            total += (1 if fused else 0) + (1 if c != 1 else 0) + (1 if c != 0 else 0)
+    return total
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -88,7 +124,8 @@ def gemm_nt(problems: Sequence[dict]) -> None:
         q.lda, q.ldb, q.ldc = p["lda"], p["ldb"], p["ldc"]
         q.batch = p.get("batch", 1)
         q.stride_a, q.stride_b, q.stride_c = p.get("stride_a", 0), p.get("stride_b", 0), p.get("stride_c", 0)
-    _lib.check(lib.aid_gemm_nt(arr, n, dt, _stream()), "aid_gemm_nt")
+    with _on(problems[0]["a"].device):
+        _lib.check(lib.aid_gemm_nt(arr, n, dt, _stream()), "aid_gemm_nt")
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -118,8 +155,9 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optio
     if out is None:
         out = torch.empty_like(x)
     c = x.shape[-1]
-    _lib.check(_lib.load().aid_layernorm(x.data_ptr(), _ptr(gamma), _ptr(beta), out.data_ptr(), x.numel() // c, c,
-                                         float(eps), _dtype_code(x), _stream()), "aid_layernorm")
+    with _on(x.device):
+        _lib.check(_lib.load().aid_layernorm(x.data_ptr(), _ptr(gamma), _ptr(beta), out.data_ptr(), x.numel() // c, c,
+                                             float(eps), _dtype_code(x), _stream()), "aid_layernorm")
     return out
 
 
@@ -143,7 +181,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
              begin: int = 0, end: int = -1, out: Optional[torch.Tensor] = None,
              accumulate: bool = False, out_scale: float = 1.0,
              frame_scale: Optional[torch.Tensor] = None, kv_map: Optional[torch.Tensor] = None,
-             softmax_scale: Optional[float] = None, n_plain: int = 0) -> torch.Tensor:
+             softmax_scale: Optional[float] = None, n_plain: int = 0, seg_executed: int = 0) -> torch.Tensor:
     """Interpolated attention core (see AidAttnArgs in include/aid_hip.h).
     q [N, S, C], k [F, L, C], vt [F, C, Lp] contiguous; coef / frame_scale fp32 device [N]."""
     lib = _lib.load()
@@ -172,9 +210,10 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
         if kv_map is not None or f != n:
             raise ValueError("inner mode needs one key/value row per frame (no kv_map)")
         k2, vt2 = torch.empty_like(k), torch.empty_like(vt)
-        _lib.check(lib.aid_lerp_kv(k.data_ptr(), vt.data_ptr(), k2.data_ptr(), vt2.data_ptr(), coef.data_ptr(), n,
-                                   begin % f, end % f, k.shape[1] * k.shape[2], vt.shape[1] * vt.shape[2], dt,
-                                   _stream()), "aid_lerp_kv")
+        with _on(q.device):
+            _lib.check(lib.aid_lerp_kv(k.data_ptr(), vt.data_ptr(), k2.data_ptr(), vt2.data_ptr(), coef.data_ptr(), n,
+                                       begin % f, end % f, k.shape[1] * k.shape[2], vt.shape[1] * vt.shape[2], dt,
+                                       _stream()), "aid_lerp_kv")
         a.k2, a.vt2 = k2.data_ptr(), vt2.data_ptr()
     a.n_frames, a.n_kv = n, f
     a.s, a.l, a.heads, a.d = s, l, heads, d
@@ -186,7 +225,9 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
     a.softmax_scale = float(d ** -0.5 if softmax_scale is None else softmax_scale)
     a.out_scale = float(out_scale)
     a.n_plain = int(n_plain)
-    _lib.check(lib.aid_attn_fwd(C.byref(a), _stream()), "aid_attn_fwd")
+    a.seg_executed = int(seg_executed)
+    with _on(q.device):
+        _lib.check(lib.aid_attn_fwd(C.byref(a), _stream()), "aid_attn_fwd")
     return out
 
 
@@ -204,13 +245,19 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
                   begin: int = 0, end: int = -1, ctx_map: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None, n_plain: int = 0,
                   ln: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor], float]] = None,
-                  residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  residual: Optional[torch.Tensor] = None, seg_executed: int = 0,
+                  ip: Optional[dict] = None) -> torch.Tensor:
     """One whole processor call: y = to_out(AID-attention(to_q(x), to_k(ctx), to_v(ctx)))
     in three launches (grouped q/k/V^T GEMM, attention core, out-proj GEMM).
     ``ln = (gamma, beta, eps)`` computes on LayerNorm(x); ``residual`` is added to the result (the transformer
-    block's norm in front of the call and its residual add after it)."""
+    block's norm in front of the call and its residual add after it).
+    ``ip`` = the IP-Adapter image branch (AidProcessorArgs.ip_*): dict(tokens=[R, T, Cc] tensor whose rows may be a
+    strided view, wk=to_k_ip weight, wv=to_v_ip weight, mode="same"|"plain", scale=float, map=int32 device [N] or None,
+    frame_scale=fp32 device [N] or None, begin=int, end=int)."""
     lib = _lib.load()
-    dev = _require_gpu(x, ctx, wq, wk, wv, wo, bo, coef, ctx_map, out, residual, *(ln[:2] if ln else ()))
+    ipt = ip or {}
+    dev = _require_gpu(x, ctx, wq, wk, wv, wo, bo, coef, ctx_map, out, residual, *(ln[:2] if ln else ()),
+                       ipt.get("tokens"), ipt.get("wk"), ipt.get("wv"), ipt.get("map"), ipt.get("frame_scale"))
     dt = _dtype_code(x)
     for t_ in (ctx, wq, wk, wv, wo, bo):
         if t_ is not None and t_.dtype != x.dtype:
@@ -235,6 +282,23 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
     a.begin, a.end = begin % nkv, end % nkv
     a.dtype = dt
     a.n_plain = int(n_plain)
+    a.seg_executed = int(seg_executed)
+    if ip is not None:
+        tok = ip["tokens"]
+        if ctx is None:
+            raise ValueError("the image branch belongs to a cross-attention call (encoder_hidden_states = (text, [ip]))")
+        if tok.ndim != 3 or tok.shape[2] != ctx.shape[2] or tok.dtype != x.dtype or tok.stride(2) != 1 \
+                or tok.stride(1) != tok.shape[2]:
+            raise ValueError("image tokens must be [rows, T, Cc] in the activation dtype with contiguous [T, Cc] rows")
+        for t_ in (ip["wk"], ip["wv"]):
+            if t_.dtype != x.dtype or not t_.is_contiguous() or tuple(t_.shape) != (c, ctx.shape[2]):
+                raise ValueError("to_k_ip / to_v_ip weights must be contiguous [C, Cc] tensors of the activation dtype")
+        a.ip, a.wk_ip, a.wv_ip = tok.data_ptr(), ip["wk"].data_ptr(), ip["wv"].data_ptr()
+        a.ip_map, a.ip_frame_scale = _ptr(ip.get("map")), _ptr(ip.get("frame_scale"))
+        a.n_ip, a.t_ip = tok.shape[0], tok.shape[1]
+        a.ip_stride = tok.stride(0) if tok.shape[0] > 1 else tok.shape[1] * tok.shape[2]
+        a.ip_mode, a.ip_scale = IP_MODES[ip["mode"]], float(ip.get("scale", 1.0))
+        a.ip_begin, a.ip_end = int(ip.get("begin", 0)) % a.n_ip, int(ip.get("end", -1)) % a.n_ip
     if ln is not None:
         g_, b_, eps = ln
         if not eps > 0:
@@ -248,12 +312,13 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
             raise ValueError("residual must be a contiguous tensor shaped like the hidden states")
         a.residual = residual.data_ptr()
     nbytes = lib.aid_processor_workspace_bytes(C.byref(a))
-    if nbytes == 0:
-        # let the library say why
-        a.workspace, a.workspace_bytes = None, 0
+    with _on(dev):
+        if nbytes == 0:
+            # let the library say why
+            a.workspace, a.workspace_bytes = None, 0
+            _lib.check(lib.aid_processor_fwd(C.byref(a), _stream()), "aid_processor_fwd")
+            raise RuntimeError("aid_processor_workspace_bytes returned 0")
+        ws = workspace(nbytes, dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(lib.aid_processor_fwd(C.byref(a), _stream()), "aid_processor_fwd")
-        raise RuntimeError("aid_processor_workspace_bytes returned 0")
-    ws = workspace(nbytes, dev)
-    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    _lib.check(lib.aid_processor_fwd(C.byref(a), _stream()), "aid_processor_fwd")
     return out

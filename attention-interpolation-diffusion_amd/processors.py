@@ -43,6 +43,11 @@ class InterpolatedAttnProcessor(nn.Module):
             assert t > 0 and t < 1, "t must be between 0 and 1"
             ts = torch.tensor([0, t, 1])
             size = 3
+        # device-side coefficient buffers, one per (device, dtype, number of coefficients, plain_tail) LAYOUT.  A buffer
+        # is allocated once and from then on only rewritten in place, so a captured hipGraph that holds its address
+        # keeps reading live values; ``_coef_dev[key] = [device tensor, values it holds, coef._version they came from]``
+        self._coef_dev: Dict[Tuple, list] = {}
+        self._ctx_cache: Dict[Tuple, Tuple] = {}
         self.size = size
         self.coef = ts
         self.is_fused = is_fused
@@ -54,8 +59,18 @@ class InterpolatedAttnProcessor(nn.Module):
         # (PAID guide prompt: [start, guide x (N-2), end] = 3 distinct contexts, sequence.py).  The keys / values of
         # a shared context are then projected once instead of once per frame.  None = one context per frame.
         self.ctx_index: Optional[Sequence[int]] = None
-        self._coef_cache: Dict[Tuple, torch.Tensor] = {}
-        self._ctx_cache: Dict[Tuple, Tuple] = {}
+
+    # ``coef`` stays a plain CPU tensor attribute like the reference's (interpolation.py:21-27, 42); assigning it
+    # (``activate(t)``, ``proc.coef = ...``) refreshes the device copies at once, so a replayed graph never sees the
+    # previous schedule.
+    @property
+    def coef(self) -> torch.Tensor:
+        return self._coef
+
+    @coef.setter
+    def coef(self, value) -> None:
+        self._coef = value if torch.is_tensor(value) else torch.as_tensor(value, dtype=torch.float32)
+        self._refresh_coef_buffers()
 
     def deactivate(self):
         self.activated = False
@@ -94,29 +109,50 @@ class InterpolatedAttnProcessor(nn.Module):
 
     # ---- build-specific helpers ------------------------------------------------------------
     def _coef_device(self, device: torch.device, dtype: torch.dtype, batch: int) -> torch.Tensor:
+        return self._coef_state(device, dtype, batch)[0]
+
+    def _coef_state(self, device: torch.device, dtype: torch.dtype, batch: int) -> Tuple[torch.Tensor, Tuple[float, ...]]:
         """``coef.to(key.device, key.dtype)`` (interpolation.py:663: coefficients are rounded to
-        the compute dtype) kept resident on the device as fp32 for the kernel."""
+        the compute dtype) kept resident on the device as fp32 for the kernel; returns (device tensor, host values)."""
         coef = self.coef
         if coef.numel() + self.plain_tail != batch:
             # the reference fails at the broadcast of the lerp (interpolation.py:664 / 774)
             raise RuntimeError(f"The size of tensor a ({coef.numel() + self.plain_tail}) must match the size of "
                                f"tensor b ({batch}) at non-singleton dimension 0")
-        key = (id(coef), coef._version, device, dtype, self.plain_tail)
-        hit = self._coef_cache.get(key)
-        if hit is None:
-            # entries are never dropped while they may be referenced: a captured hipGraph keeps reading the device
-            # tensor it was captured with (the loop alternates between a few (schedule, plain_tail) combinations)
-            if len(self._coef_cache) >= _CACHE_ENTRIES:
-                self._coef_cache.pop(next(iter(self._coef_cache)))
-            hit = coef.detach().to(torch.float32).to(dtype).to(torch.float32)
-            if self.plain_tail:                       # negative coefficient = PLAIN rider frame (aid_hip.h)
-                hit = torch.cat([hit, -torch.ones(self.plain_tail)])
-            hit = hit.to(device).contiguous()
-            self._coef_cache[key] = hit
-        return hit
+        key = (device, dtype, coef.numel(), self.plain_tail)
+        ent = self._coef_dev.get(key)
+        if ent is None:
+            vals = _coef_values(coef, dtype, self.plain_tail)
+            ent = [torch.tensor(vals, dtype=torch.float32).to(device), vals, coef._version]
+            self._coef_dev[key] = ent
+        elif ent[2] != coef._version:                 # the tensor was mutated in place (proc.coef[1] = t)
+            _rewrite(ent, _coef_values(coef, dtype, self.plain_tail), coef._version)
+        return ent[0], ent[1]
+
+    def _refresh_coef_buffers(self) -> None:
+        """After ``coef`` was re-assigned: bring every device buffer of the matching layout up to date in place."""
+        coef = self._coef
+        for (device, dtype, n, tail), ent in self._coef_dev.items():
+            if n == coef.numel():
+                _rewrite(ent, _coef_values(coef, dtype, tail), coef._version)
 
 
-_CACHE_ENTRIES = 16      # distinct (schedule, plain_tail) / context maps a processor keeps resident on the device
+def _coef_values(coef: torch.Tensor, dtype: torch.dtype, plain_tail: int) -> Tuple[float, ...]:
+    """Host values of a device coefficient buffer: ``coef`` rounded to the compute dtype (interpolation.py:663), then
+    ``plain_tail`` negative entries (negative coefficient = PLAIN rider frame, aid_hip.h)."""
+    vals = coef.detach().to(torch.float32).cpu().to(dtype).to(torch.float32).tolist()
+    return tuple(vals) + (-1.0,) * plain_tail
+
+
+def _rewrite(ent: list, vals: Tuple[float, ...], version: int) -> None:
+    """Update a device coefficient buffer IN PLACE (its address may be baked into captured graphs)."""
+    if vals != ent[1]:
+        if torch.cuda.is_available() and ent[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the coefficient schedule changed inside a stream capture; call the processor once "
+                               "eagerly (or assign `coef` / activate(t)) before capturing")
+        ent[0].copy_(torch.tensor(vals, dtype=torch.float32))
+        ent[1] = vals
+    ent[2] = version
 
 
 def _shared_context(cache: Dict, ctx_index, ctx: torch.Tensor, batch: int):
@@ -130,8 +166,8 @@ def _shared_context(cache: Dict, ctx_index, ctx: torch.Tensor, batch: int):
     key = (tuple(idx), ctx.device)
     hit = cache.get(key)
     if hit is None:
-        if len(cache) >= _CACHE_ENTRIES:          # see _coef_device: captured graphs hold on to these tensors
-            cache.pop(next(iter(cache)))
+        # keyed by the map's VALUES and never dropped: a captured hipGraph keeps reading the device tensors it was
+        # captured with, and a run uses a handful of distinct maps (a few hundred bytes each)
         first = [idx.index(r) for r in range(n_distinct)]
         hit = (torch.tensor(idx, dtype=torch.int32, device=ctx.device),
                torch.tensor(first, dtype=torch.long, device=ctx.device))
@@ -204,12 +240,12 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
               attention_mask, temb, mode: str, ctx_index=None, ln=None, add_to=None):
     residual, x, ctx, shape4 = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
     wq, wk, wv, wo, bo = _weights(attn)
-    coef = None
+    coef = vals = None
     if mode != "plain":
-        coef = proc._coef_device(x.device, x.dtype, x.shape[0])
+        coef, vals = proc._coef_state(x.device, x.dtype, x.shape[0])
     n_aid = proc.coef.numel()
     begin, end = 0, (n_aid - 1) if mode != "plain" else -1
-    ctx_map = None
+    ctx_map = idx = None
     ctx_index = proc.ctx_index if ctx_index is None else ctx_index
     if ctx is not None and ctx_index is not None:
         ctx, ctx_map, idx = _shared_context(proc._ctx_cache, ctx_index, ctx, x.shape[0])
@@ -217,10 +253,11 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
             begin, end = idx[0], idx[n_aid - 1]       # end-point rows of the key / value tensors
     elif ctx is not None:
         ctx = ctx.contiguous()
-    y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode,
-                          fused=proc.is_fused if mode != "plain" else False, coef=coef,
+    fused = proc.is_fused if mode != "plain" else False
+    y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode, fused=fused, coef=coef,
                           begin=begin, end=end, ctx_map=ctx_map,
-                          n_plain=proc.plain_tail if mode != "plain" else 0, ln=ln, residual=add_to)
+                          n_plain=proc.plain_tail if mode != "plain" else 0, ln=ln, residual=add_to,
+                          seg_executed=ops.executed_segments(mode, fused, vals, x.shape[0], idx, begin, end))
     return _epilogue(attn, y, residual, shape4)
 
 
@@ -310,8 +347,86 @@ class InnerInterpolatedAttnProcessor(InterpolatedAttnProcessor):
 
 
 # ---------------------------------------------------------------------------------------------
-# IP-Adapter variants (batch hard-wired to 3 by the reference)
+# IP-Adapter variants.  The reference hard-wires a batch of 3 (literal ``expand(3, ...)``, ``[::3]``, ``[6:9]``;
+# SURVEY.md App. D5).  Here the batch is ``coef.numel()`` frames and the image-embedding tensor ``[R, 1, T, Cc]`` holds
+# r = R / N copies per frame (r = 3, R = 9 in the reference's pipelines): ``[::3]`` becomes ``[::r]`` and ``[6:9]`` the
+# rows of the last frame — identical for N = 3, and an N-frame sequence (one image-embedding row group per frame) runs
+# too.  Every variant is ONE library call (aid_processor_fwd with the ip_* fields): the image keys / values are projected
+# in the same grouped launch as q / k / V^T and the image attention accumulates into the text attention's output.
 # ---------------------------------------------------------------------------------------------
+def _split_ip(encoder_hidden_states, num_tokens):
+    """interpolation.py:255-266: (text, [ip]) tuple or a concatenated tensor split at ``shape[1] - num_tokens[0]``."""
+    if encoder_hidden_states is None:
+        return None, None
+    if isinstance(encoder_hidden_states, tuple):
+        return encoder_hidden_states
+    end_pos = encoder_hidden_states.shape[1] - num_tokens[0]
+    return encoder_hidden_states[:, :end_pos, :], [encoder_hidden_states[:, end_pos:, :]]
+
+
+def _ip_token_rows(ip_list) -> torch.Tensor:
+    """ip_hidden_states[0] as [R, E*T, Cc]: a 4-D [R, E, T, Cc] input folds E into the token axis
+    (head_to_batch_dim on 4-D tensors, interpolation.py:334-341)."""
+    if len(ip_list) != 1:
+        raise NotImplementedError("one IP-Adapter per layer (the reference reads to_k_ip[0] / scale[0] only)")
+    rows = ip_list[0]
+    if rows.ndim == 4:
+        rows = rows.reshape(rows.shape[0], rows.shape[1] * rows.shape[2], rows.shape[3])
+    if rows.ndim != 3:
+        raise RuntimeError(f"image embeddings must be [R, T, Cc] or [R, E, T, Cc], got {tuple(rows.shape)}")
+    return rows.contiguous()
+
+
+class HipIPAdapterAttnProcessor(nn.Module):
+    """What diffusers' ``IPAdapterAttnProcessor2_0`` computes (third-party, restated), on the HIP
+    kernels: plain text attention + ``scale[0]`` x plain attention over the frame's image tokens.  The reference's IP
+    processors call exactly this when de-activated (interpolation.py:248-251, 425-428) — every unconditional pass and
+    every post-warm-up step of an IP run.  An image-embedding tensor with more rows than frames (the pipelines'
+    ``[9, 1, T, Cc]`` for a batch of 3) is folded like diffusers' ``view(batch, -1, heads, head_dim)`` does: frame i
+    attends over the tokens of rows ``[i r, (i + 1) r)``.
+    Owns (or shares, see :meth:`wrap`) ``to_k_ip`` / ``to_v_ip`` / ``scale`` / ``num_tokens``."""
+
+    def __init__(self, hidden_size: Optional[int] = None, cross_attention_dim: Optional[int] = None,
+                 num_tokens=(4,), scale=1.0, dtype=None, device=None):
+        super().__init__()
+        self.num_tokens = tuple(num_tokens) if isinstance(num_tokens, (tuple, list)) else (num_tokens,)
+        self.scale = list(scale) if isinstance(scale, (tuple, list)) else [scale] * len(self.num_tokens)
+        if hidden_size is not None:
+            kw = dict(dtype=dtype, device=device)
+            self.to_k_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False, **kw)
+                                          for _ in self.num_tokens])
+            self.to_v_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False, **kw)
+                                          for _ in self.num_tokens])
+
+    @classmethod
+    def wrap(cls, ip_attn) -> "HipIPAdapterAttnProcessor":
+        """Share the weights / scale list / token counts of an installed IP-Adapter processor (diffusers' or a shim)."""
+        self = cls(num_tokens=ip_attn.num_tokens, scale=ip_attn.scale)
+        self.scale = ip_attn.scale                     # the SAME list: pipeline.set_ip_adapter_scale keeps working
+        self.to_k_ip, self.to_v_ip = ip_attn.to_k_ip, ip_attn.to_v_ip
+        return self
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 scale: float = 1.0, ip_adapter_masks=None):
+        if ip_adapter_masks is not None:
+            raise NotImplementedError("ip_adapter_masks are not supported by the HIP path")
+        text, ip = _split_ip(encoder_hidden_states, self.num_tokens)
+        residual, x, text, shape4 = _prologue(attn, hidden_states, text, attention_mask, temb)
+        wq, wk, wv, wo, bo = _weights(attn)
+        branch = None
+        if ip is not None and float(self.scale[0]) != 0.0:
+            rows = _ip_token_rows(ip)
+            n = x.shape[0]
+            if rows.shape[0] % n:
+                raise RuntimeError(f"{rows.shape[0]} image-embedding rows do not fold into a batch of {n}")
+            tokens = rows.reshape(n, -1, rows.shape[-1])          # diffusers: ip_key.view(batch, -1, heads, head_dim)
+            branch = dict(tokens=tokens, wk=self.to_k_ip[0].weight, wv=self.to_v_ip[0].weight, mode="plain",
+                          scale=float(self.scale[0]))
+        y = ops.processor_fwd(x, None if text is None else text.contiguous(), wq, wk, wv, wo, bo, attn.heads,
+                              mode="plain", ip=branch)
+        return _epilogue(attn, y, residual, shape4)
+
+
 class _IPBase(InterpolatedAttnProcessor):
     def __init__(self, t=None, size=7, is_fused=False, alpha=1, beta=1, ip_attn=None):
         super().__init__(t=t, size=size, is_fused=is_fused, alpha=alpha, beta=beta)
@@ -319,33 +434,59 @@ class _IPBase(InterpolatedAttnProcessor):
         self.scale = ip_attn.scale if hasattr(ip_attn, "scale") else None
         self.ip_attn = ip_attn
 
-    def _split(self, encoder_hidden_states):
-        """interpolation.py:255-266: (text, [ip]) tuple or a concatenated tensor."""
-        if encoder_hidden_states is None:
-            return None, None
-        if isinstance(encoder_hidden_states, tuple):
-            return encoder_hidden_states
-        end_pos = encoder_hidden_states.shape[1] - self.num_tokens[0]
-        return encoder_hidden_states[:, :end_pos, :], [encoder_hidden_states[:, end_pos:, :]]
+    def _fallback(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb):
+        """De-activated: the wrapped processor, like the reference (interpolation.py:248-251).  A wrapped object that
+        cannot be called (a bare weight holder) runs the HIP IP-Adapter attention on its weights instead."""
+        if callable(self.ip_attn) and not getattr(self.ip_attn, "weights_only", False):
+            return self.ip_attn(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+        if hasattr(self.ip_attn, "to_k_ip"):
+            return HipIPAdapterAttnProcessor.wrap(self.ip_attn)(attn, hidden_states, encoder_hidden_states,
+                                                                attention_mask, temb)
+        return HipAttnProcessor()(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
 
-    def _ip_kv(self, rows: torch.Tensor):
-        """to_k_ip[0] / to_v_ip[0] on the selected image-embedding rows; a 4-D [B, E, T, Cc] input
-        folds E into the token axis (head_to_batch_dim on 4-D, interpolation.py:334-341)."""
-        if rows.ndim == 4:
-            rows = rows.reshape(rows.shape[0], rows.shape[1] * rows.shape[2], rows.shape[3])
-        rows = rows.contiguous()
-        return ops.project_kv(rows, self.ip_attn.to_k_ip[0].weight, self.ip_attn.to_v_ip[0].weight) + (rows.shape[1],)
+    def _frames(self, x) -> int:
+        n = self.coef.numel()
+        if x.shape[0] != n:
+            raise RuntimeError(f"the IP processors run a batch of coef.numel() = {n} frames "
+                               f"[start, ..., end] (the reference hard-wires 3, interpolation.py:300-303); "
+                               f"got a batch of {x.shape[0]}")
+        return n
 
-    def _text_qkv(self, attn, x, text):
-        wq, wk, wv, _, _ = _weights(attn)
-        e = x if text is None else text.contiguous()
-        q = ops.linear(x, wq)
-        k, vt = ops.project_kv(e, wk, wv)
-        return q, k, vt, e.shape[1]
+    def _image_rows(self, ip, n: int, which: str):
+        """Rows of the image-embedding tensor a variant attends with, as a (strided) [rows, T', Cc] view plus the
+        frame -> row map (None = identity).  ``per_frame``: row group i of frame i — the reference's ``[::3]``
+        (interpolation.py:330-331, 502-505); ``last``: the rows of the END frame — its ``[6:9]`` (:137-138, 187-188)."""
+        rows = _ip_token_rows(ip)
+        if rows.shape[0] % n:
+            raise RuntimeError(f"{rows.shape[0]} image-embedding rows for {n} frames")
+        r = rows.shape[0] // n
+        if which == "per_frame":
+            return rows[::r], None
+        if r == n:                                       # N = 3, R = 9: literally rows [6:9], one per frame
+            return rows[rows.shape[0] - r:], None
+        last = rows[r * (n - 1): r * (n - 1) + 1]
+        return last, _zeros_map(self._ctx_cache, n, rows.device)
 
-    def _finish(self, attn, o, residual, shape4):
-        _, _, _, wo, bo = _weights(attn)
-        return _epilogue(attn, ops.linear(o, wo, bo), residual, shape4)
+    def _call(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, mode, branch_of):
+        text, ip = _split_ip(encoder_hidden_states, self.num_tokens)
+        residual, x, text, shape4 = _prologue(attn, hidden_states, text, attention_mask, temb)
+        n = self._frames(x)
+        wq, wk, wv, wo, bo = _weights(attn)
+        coef, vals = self._coef_state(x.device, x.dtype, x.shape[0])
+        fused = self.is_fused if mode != "plain" else False
+        branch = branch_of(ip, n, coef) if ip is not None else None
+        y = ops.processor_fwd(x, None if text is None else text.contiguous(), wq, wk, wv, wo, bo, attn.heads,
+                              mode=mode, fused=fused, coef=coef, begin=0, end=n - 1, ip=branch,
+                              seg_executed=ops.executed_segments(mode, fused, vals, n, None, 0, n - 1))
+        return _epilogue(attn, y, residual, shape4)
+
+
+def _zeros_map(cache, n: int, device) -> torch.Tensor:
+    key = ("zeros", n, device)
+    hit = cache.get(key)
+    if hit is None:
+        hit = cache[key] = torch.zeros(n, dtype=torch.int32, device=device)
+    return hit
 
 
 class OuterInterpolatedIPAttnProcessor(_IPBase):
@@ -354,20 +495,13 @@ class OuterInterpolatedIPAttnProcessor(_IPBase):
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
         if not self.activated:
-            return self.ip_attn(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
-        text, ip = self._split(encoder_hidden_states)
-        residual, x, text, shape4 = _prologue(attn, hidden_states, text, attention_mask, temb)
-        coef = self._coef_device(x.device, x.dtype, x.shape[0])
-        if x.shape[0] != 3:
-            raise RuntimeError("the IP processors are defined for a batch of 3 [start, target, end] "
-                               "(interpolation.py:300-303)")
-        q, k, vt, l = self._text_qkv(attn, x, text)
-        o = ops.attn_fwd(q, k, vt, attn.heads, l=l, mode="outer", fused=self.is_fused, coef=coef)
-        if ip is not None:
-            kip, vtip, t_ip = self._ip_kv(ip[0][::3])                       # interpolation.py:330-331
-            ops.attn_fwd(q, kip, vtip, attn.heads, l=t_ip, mode="outer", fused=self.is_fused, coef=coef,
-                         out=o, accumulate=True, out_scale=float(self.scale[0]))   # :364-372 (linear in O)
-        return self._finish(attn, o, residual, shape4)
+            return self._fallback(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+
+        def branch(ip, n, coef):                                            # interpolation.py:329-367 (linear in O)
+            tokens, _ = self._image_rows(ip, n, "per_frame")
+            return dict(tokens=tokens, wk=self.ip_attn.to_k_ip[0].weight, wv=self.ip_attn.to_v_ip[0].weight,
+                        mode="same", scale=float(self.scale[0]), begin=0, end=n - 1)
+        return self._call(attn, hidden_states, encoder_hidden_states, attention_mask, temb, "outer", branch)
 
 
 class InnerInterpolatedIPAttnProcessor(_IPBase):
@@ -377,47 +511,31 @@ class InnerInterpolatedIPAttnProcessor(_IPBase):
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
         if not self.activated:
-            return self.ip_attn(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
-        text, ip = self._split(encoder_hidden_states)
-        residual, x, text, shape4 = _prologue(attn, hidden_states, text, attention_mask, temb)
-        coef = self._coef_device(x.device, x.dtype, x.shape[0])
-        if x.shape[0] != 3:
-            raise RuntimeError("the IP processors are defined for a batch of 3 [start, target, end] "
-                               "(interpolation.py:477-480)")
-        if ip is not None and not self.is_fused:
-            raise RuntimeError("InnerInterpolatedIPAttnProcessor needs is_fused=True when image embeddings are "
-                               "passed: the reference's image branch multiplies un-split keys "
-                               "(batch1 dim mismatch in bmm, interpolation.py:525)")
-        q, k, vt, l = self._text_qkv(attn, x, text)
-        o = ops.attn_fwd(q, k, vt, attn.heads, l=l, mode="inner", fused=self.is_fused, coef=coef)
-        if ip is not None:
-            kip, vtip, t_ip = self._ip_kv(ip[0][::3])                       # interpolation.py:502-505
-            ops.attn_fwd(q, kip, vtip, attn.heads, l=t_ip, mode="plain", out=o, accumulate=True,
-                         out_scale=float(self.scale[0]))                    # :525-530
-        return self._finish(attn, o, residual, shape4)
+            return self._fallback(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+
+        def branch(ip, n, coef):                                            # interpolation.py:502-505, 525-530
+            if not self.is_fused:
+                raise RuntimeError("InnerInterpolatedIPAttnProcessor needs is_fused=True when image embeddings are "
+                                   "passed: the reference's image branch multiplies un-split keys "
+                                   "(batch1 dim mismatch in bmm, interpolation.py:525)")
+            tokens, _ = self._image_rows(ip, n, "per_frame")
+            return dict(tokens=tokens, wk=self.ip_attn.to_k_ip[0].weight, wv=self.ip_attn.to_v_ip[0].weight,
+                        mode="plain", scale=float(self.scale[0]))
+        return self._call(attn, hidden_states, encoder_hidden_states, attention_mask, temb, "inner", branch)
 
 
 class ScaleControlIPAttnProcessor(_IPBase):
     r"""Image-prompt scale control (interpolation.py:51-211): text attention is outer-interpolated
-    (activated) or plain (de-activated); the image attention of rows [6:9] is added with the
+    (activated) or plain (de-activated); the image attention of the END frame's rows ([6:9]) is added with the
     per-frame coefficient."""
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
-        text, ip = self._split(encoder_hidden_states)
-        residual, x, text, shape4 = _prologue(attn, hidden_states, text, attention_mask, temb)
-        coef = self._coef_device(x.device, x.dtype, x.shape[0])
-        q, k, vt, l = self._text_qkv(attn, x, text)
-        if self.activated:
-            if x.shape[0] != 3:
-                raise RuntimeError("the IP processors are defined for a batch of 3 (interpolation.py:152-155)")
-            o = ops.attn_fwd(q, k, vt, attn.heads, l=l, mode="outer", fused=self.is_fused, coef=coef)
-        else:
-            o = ops.attn_fwd(q, k, vt, attn.heads, l=l, mode="plain")
-        if ip is not None:
-            kip, vtip, t_ip = self._ip_kv(ip[0][6:9])                       # interpolation.py:137-138 / 187-188
-            ops.attn_fwd(q, kip, vtip, attn.heads, l=t_ip, mode="plain", out=o, accumulate=True,
-                         frame_scale=coef)                                  # :146-150 / :196
-        return self._finish(attn, o, residual, shape4)
+        def branch(ip, n, coef):                                            # interpolation.py:137-150 / 187-196
+            tokens, row_map = self._image_rows(ip, n, "last")
+            return dict(tokens=tokens, wk=self.ip_attn.to_k_ip[0].weight, wv=self.ip_attn.to_v_ip[0].weight,
+                        mode="plain", scale=1.0, frame_scale=coef, map=row_map)
+        return self._call(attn, hidden_states, encoder_hidden_states, attention_mask, temb,
+                          "outer" if self.activated else "plain", branch)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -445,6 +563,35 @@ def load_aid(unet, t: Optional[float] = 0.5, is_fused: bool = True, atype: str =
                                                          original_attn=orig)
         else:
             raise ValueError(f"atype must be 'fused_outer' or 'fused_inner', got {atype!r}")
+    unet.set_attn_processor(procs)
+
+
+def load_aid_ip_adapter(unet, t: Optional[float] = 0.5, is_fused: bool = True, early: str = "fused_outer",
+                        size: int = 7, alpha: float = 1, beta: float = 1, keep_original: bool = False) -> None:
+    """Wrap every attention layer of a UNet whose IP-Adapter is ALREADY loaded (diffusers' ``load_ip_adapter`` —
+    third-party, the reference calls it first, pipeline_interpolated_sd.py:986-992) with the IP variant ``early``
+    selects (:993-1007): ``fused_outer`` / ``fused_inner`` / ``scale_control``.  The wrapped processor becomes
+    ``ip_attn`` like in the reference; by default its HIP equivalent takes its place (sharing the adapter weights and
+    the scale list) so the de-activated passes stay on the HIP kernels: IP-Adapter cross-attention layers get a
+    :class:`HipIPAdapterAttnProcessor`, the other layers a :class:`HipAttnProcessor`.  ``keep_original=True`` keeps
+    the installed processor itself."""
+    classes = {"fused_outer": OuterInterpolatedIPAttnProcessor, "fused_inner": InnerInterpolatedIPAttnProcessor,
+               "scale_control": ScaleControlIPAttnProcessor}
+    if early not in classes:
+        raise ValueError(f"early must be one of {sorted(classes)}, got {early!r}")
+    procs = {}
+    current = unet.attn_processors
+    for name, cur in current.items():
+        if name.startswith("encoder"):
+            procs[name] = cur
+            continue
+        if keep_original:
+            ip_attn = cur
+        elif hasattr(cur, "to_k_ip"):
+            ip_attn = cur if isinstance(cur, HipIPAdapterAttnProcessor) else HipIPAdapterAttnProcessor.wrap(cur)
+        else:
+            ip_attn = HipAttnProcessor()
+        procs[name] = classes[early](t=t, size=size, is_fused=is_fused, alpha=alpha, beta=beta, ip_attn=ip_attn)
     unet.set_attn_processor(procs)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: interpolation-frames/sec (50-step) of the AID attention stack on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model sd15|sdxl] [--early fused_inner|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload sdxl|sd15|seq16|ip] [--early ...]
 
 One "step" = one denoising step of the interpolation run = the ordered attention calls of one UNet
 forward (SD1.5 32 calls, SDXL 140 calls) executed twice: the conditional pass (AID
@@ -10,35 +10,49 @@ unconditional pass (plain), exactly as the reference loop toggles them
 (pipeline_interpolated_sd.py:1831-1870).  Weights / hidden states / text context are synthetic
 (seed 1002) and resident in HBM before the timed region.
 
-Default workload = BASELINE.json configs[1]: SD1.5 512x512, 7-frame fused-inner AID, 50 steps, fp16
-on 1 GPU.  ``--model sdxl`` = configs[2] (SDXL 1024x1024, 7-frame fused-outer, bf16).
-For N > 1 (launched under torch.distributed.run) ONE sequence of 7*N frames is sharded by frame
-with replicated end points (dist.py): zero per-layer communication, one broadcast of the conditioning
-before and one all_gather of the owned outputs after the K steps (inside the timed region).
+Workloads (BASELINE.json configs):
+  sdxl   configs[2]  SDXL 1024x1024, 7-frame PAID (guide prompt) fused-outer, bf16          <- default at --gpus 1
+  sd15   configs[1]  SD1.5 512x512, 7-frame fused-inner AID, fp16   (also reported under "also" by the default run)
+  seq16  configs[3]  SDXL 1024x1024, ONE 16-frame sequence sharded by frame over the ranks  <- default at --gpus N > 1
+  ip     configs[4]  SDXL + IP-Adapter image-conditioned morphing, 8-frame outer-IP, image-embed cross-attention
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N ranks
+(one per GPU, backend nccl = RCCL); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  The sequence is sharded by
+frame with replicated end points (dist.py): zero per-layer communication, one broadcast of the conditioning before and
+one all_gather of the owned outputs after the steps (inside the timed region).  `--weak` keeps 7 owned frames per GPU.
 
-Rank 0 prints ONE JSON line (see the task contract); N=1 additionally measures
-  roofline     — HIP-event timing of every kernel launch of one AID step + one plain step
-                 (aid_profile_begin/end in the C ABI) -> achieved algorithmic TFLOP/s of the dominant kernel
-  cpu_baseline — the numpy oracle (oracle/aid_oracle.py, "port") timed on the host cores on a bounded
+The timed region is EXACTLY K steps, repeated `repeats` times back to back when K steps take less than a second
+(ms_per_step is the mean over K * repeats steps).  Rank 0 prints ONE JSON line; N = 1 additionally measures
+  roofline     — HIP-event timing of every kernel launch of one AID step + one plain step (aid_profile_begin/end in the
+                 C ABI): algorithmic AND executed TFLOP/s per kernel symbol, the dominant symbol reported on top
+  cpu_baseline — the threaded CPU port of the path (oracle/aid_cpu_port.py, "port") timed on the host cores on a bounded
                  sample and extrapolated to the same 50-step unit.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16 / bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
-DEFAULT_EARLY = {"sd15": "fused_inner", "sdxl": "fused_outer"}
-DTYPES = {"sd15": torch.float16, "sdxl": torch.bfloat16}
+WORKLOADS = {
+    #          stack   dtype   early          frames  guide  what
+    "sdxl":  ("sdxl", "bf16", "fused_outer", 7, True,
+              "BASELINE configs[2]: SDXL-base 1024x1024 attention stack (140 attention calls / UNet pass), 7-frame PAID"),
+    "sd15":  ("sd15", "f16", "fused_inner", 7, False,
+              "BASELINE configs[1]: SD1.5 512x512 attention stack (32 attention calls / UNet pass), 7-frame AID"),
+    "seq16": ("sdxl", "bf16", "fused_outer", 16, True,
+              "BASELINE configs[3]: SDXL 1024x1024, ONE 16-frame PAID sequence sharded by frame over the GPUs"),
+    "ip":    ("sdxl", "bf16", "fused_outer", 8, False,
+              "BASELINE configs[4]: SDXL + IP-Adapter image-conditioned morphing, 8-frame outer-IP, image-embed cross-attention"),
+}
 
 
 def parse():
@@ -46,28 +60,53 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl"])
-    ap.add_argument("--early", default=None, help="pure_inner|fused_inner|pure_outer|fused_outer")
-    ap.add_argument("--frames-per-gpu", type=int, default=7)
+    ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
+    ap.add_argument("--model", default=None, choices=["sd15", "sdxl"], help="alias of --workload sd15 / sdxl")
+    ap.add_argument("--early", default=None, help="pure_inner|fused_inner|pure_outer|fused_outer (ip: fused_outer|fused_inner|scale_control)")
+    ap.add_argument("--frames", type=int, default=None, help="total frames of the sequence (default: the workload's)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: 7 owned frames per GPU (7 N frames) instead of configs[3]")
+    ap.add_argument("--frames-per-gpu", type=int, default=7, help="--weak: owned frames per GPU")
     ap.add_argument("--warmup-ratio", type=float, default=0.5)
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K steps until the timed region is this long")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--separate-passes", action="store_true",
                     help="run the cond and the uncond pass as two UNet calls like the reference loop "
                          "(default: one call over [cond ; uncond], same work, same results)")
     ap.add_argument("--guide-prompt", default="auto", choices=["auto", "on", "off"],
-                    help="PAID: interior frames share the guide prompt's text context (3 distinct contexts); "
-                         "auto = on for sdxl (BASELINE configs[2]), off for sd15 (configs[1]: per-frame embeddings)")
+                    help="PAID: interior frames share the guide prompt's text context (3 distinct contexts)")
+    ap.add_argument("--ip-tokens", type=int, default=4, help="ip: image tokens per frame (4: ImageProjection, 16: plus)")
     ap.add_argument("--sublayers", default="off", choices=["off", "steps", "fused"],
                     help="widened workload (SURVEY.md 8f.2): every attention call with the LayerNorm in front of it and the "
                          "residual add behind it, as three steps (torch LayerNorm / call / torch add) or as ONE library call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary SD1.5 measurement of the default run")
     return ap.parse_args()
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run."""
+    import torch
+    one_dev = os.environ.get("AID_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not one_dev:
+        print(f"[bench] --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to report a {args.gpus}-GPU number "
+              "(AID_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0 over gloo for development)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ----------------------------------------------------------------------------------------------------
 def make_inputs(unet, n_frames, dtype, device, seed=1002, n_ctx=None):
     """Hidden state per resolution level ~ N(0,1) (post-LayerNorm scale) and ``n_ctx`` text contexts ~ N(0,1)
     (one per frame, or the 3 distinct ones [start, guide, end] of a PAID run)."""
+    import torch
     g = torch.Generator(device="cpu").manual_seed(seed)
     n_ctx = n_frames if n_ctx is None else n_ctx
     xs = {}
@@ -75,22 +114,23 @@ def make_inputs(unet, n_frames, dtype, device, seed=1002, n_ctx=None):
         xs[(s, c)] = torch.randn(n_frames, s, c, generator=g).to(dtype).to(device)
     cond = torch.randn(n_ctx, unet.text_len, unet.cross_dim, generator=g).to(dtype).to(device)
     uncond = torch.randn(n_ctx, unet.text_len, unet.cross_dim, generator=g).to(dtype).to(device)
-    return xs, cond, uncond
+    return xs, cond, uncond, g
 
 
-def recorded_traffic(model, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC collection (profiles/r01_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, gfx950 x2 correction
-    on FETCH_SIZE applied).  PMC counters cannot be collected from inside this process; null if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["models"][model][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+def recorded_traffic(stack, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC collection (profiles/r02_pmc.json, written by
+    tools/pmc_collect.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, gfx950 x2
+    correction on FETCH_SIZE applied).  PMC counters cannot be collected from inside this process; null if absent."""
+    for name in ("r02_pmc.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["models"][stack][kernel]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
-def roofline_pass(loop, aid_amd):
+def roofline_pass(loop, aid_amd, torch):
     """HIP-event timing (on the launch stream) of every kernel of one AID step + one plain step."""
     lib = aid_amd._lib.load()
     was = loop.use_graphs
@@ -100,105 +140,139 @@ def roofline_pass(loop, aid_amd):
     lib.aid_profile_begin()
     loop.step(0)                                                 # AID step
     loop.step(loop.num_inference_steps - 1)                      # plain step
-    buf = (aid_amd._lib.AidProfileEntry * 4096)()
-    n = lib.aid_profile_end(buf, 4096)
+    buf = (aid_amd._lib.AidProfileEntry * 8192)()
+    n = lib.aid_profile_end(buf, 8192)
     loop.use_graphs = was
     if n < 0:
         raise RuntimeError(lib.aid_strerror(n).decode())
     agg = {}
     for e in buf[:n]:
-        a = agg.setdefault(e.kernel.decode(), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        a["ms"] += e.ms; a["flops"] += e.flops; a["bytes"] += e.bytes; a["launches"] += 1
+        a = agg.setdefault(e.kernel.decode(), dict(ms=0.0, flops=0.0, flops_executed=0.0, bytes=0.0, launches=0))
+        a["ms"] += e.ms; a["flops"] += e.flops; a["flops_executed"] += e.flops_executed
+        a["bytes"] += e.bytes; a["launches"] += 1
     return agg
 
 
-def cpu_baseline(model, n_frames, early, steps, warmup_ratio):
-    """Oracle ("port") on the host cores: one transformer block (self + cross call) per resolution level,
-    AID mode and plain mode, on the 3-frame sub-batch [first, middle, last] of the same synthetic inputs,
-    scaled by n_frames/3 and by the block counts to one UNet pass, then to the 50-step unit."""
-    import numpy as np
+def roofline_object(agg, stack):
+    dom = max(agg, key=lambda k: agg[k]["ms"])          # the kernel SYMBOL with the largest total time
+    d = agg[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    ach_x = d["flops_executed"] / (d["ms"] * 1e-3) / 1e12
+    tot_ms = sum(v["ms"] for v in agg.values())
+    return {
+        "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+        "achieved_executed": ach_x, "frac_executed": ach_x / MFMA_PEAK_TFLOPS,
+        "traffic": recorded_traffic(stack, dom), "kernel": dom, "launches": d["launches"],
+        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+        "avg_launch_us": d["ms"] * 1e3 / d["launches"], "avg_launch_gflop": d["flops"] / d["launches"] / 1e9,
+        "avg_launch_gflop_executed": d["flops_executed"] / d["launches"] / 1e9,
+        "share_of_kernel_time": d["ms"] / tot_ms,
+        "note": ("per kernel symbol; `achieved` = algorithmic flops (SURVEY.md §8d: a fused-outer frame counts 3 key "
+                 "segments, fused-inner 2) / HIP-event time on the launch stream over 1 AID step + 1 plain step; "
+                 "`*_executed` counts the segment passes the kernel really runs (a fused END-POINT frame runs 1)"),
+        "kernels": {k: {"ms": round(v["ms"], 4), "launches": v["launches"],
+                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                        "tflops_executed": round(v["flops_executed"] / (v["ms"] * 1e-3) / 1e12, 1),
+                        "min_bytes_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in sorted(agg.items())},
+        "stack_tflops": sum(v["flops"] for v in agg.values()) / (tot_ms * 1e-3) / 1e12,
+        "stack_tflops_executed": sum(v["flops_executed"] for v in agg.values()) / (tot_ms * 1e-3) / 1e12,
+        "kernel_ms_per_2steps": tot_ms,
+    }
+
+
+def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
+    """The CPU port ("port", oracle/aid_cpu_port.py: the oracle's arithmetic on torch CPU ops) on the host cores with
+    torch.set_num_threads(all cores): ONE transformer block (self + cross call) per resolution level in the AID mode and
+    in plain mode on all `n_frames` frames of the same synthetic inputs (median of 3 where a call takes < 2 s, single
+    shot otherwise), scaled by the block counts to one UNet pass and by the pass counts to the 50-step unit."""
+    import torch
+    from oracle import aid_cpu_port as P
     from oracle import aid_oracle as O
     from aid_amd.attn_shim import MODEL_SPECS
-    spec = MODEL_SPECS[model]
-    rs = np.random.RandomState(1002)
+    spec = MODEL_SPECS[stack]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1002)
     mode = "outer" if early.endswith("outer") else "inner"
     fused = early.startswith("fused")
-    coef = O.beta_coefs(n_frames, steps, steps)
-    sub = np.asarray([0.0, float(coef[n_frames // 2]), 1.0], dtype=np.float32)
+    coef = torch.from_numpy(O.beta_coefs(n_frames, steps, steps))
     levels = {}
     for loc, nblk, s, c, h in spec["layers"]:
-        levels.setdefault((s, c, h), 0)
-        levels[(s, c, h)] += nblk
+        levels[(s, c, h)] = levels.get((s, c, h), 0) + nblk
     t_aid = t_plain = 0.0
     t0_all = time.time()
-    for (s, c, h), nblk in levels.items():
+    shots = []
+
+    def timed(fn):
+        t0 = time.time(); fn(); first = time.time() - t0
+        if first >= 2.0 or time.time() - t0_all > budget_s:
+            shots.append(1)
+            return first
+        ts = [first]
+        for _ in range(2):
+            t0 = time.time(); fn(); ts.append(time.time() - t0)
+        shots.append(3)
+        return sorted(ts)[1]
+
+    for (s, c, h), nblk in sorted(levels.items()):          # small levels first, the S = 4096 calls last
         cc = spec["cross_dim"]
-        x = rs.standard_normal((3, s, c)).astype(np.float32)
-        ctx = rs.standard_normal((3, spec["text_len"], cc)).astype(np.float32)
-        ws = O.AttnWeights(*(rs.standard_normal(sh).astype(np.float32) / np.sqrt(sh[-1]) for sh in
-                             ((c, c), (c, c), (c, c), (c, c))), rs.standard_normal(c).astype(np.float32) * .01, h)
-        wx = O.AttnWeights(ws.wq, rs.standard_normal((c, cc)).astype(np.float32) / np.sqrt(cc),
-                           rs.standard_normal((c, cc)).astype(np.float32) / np.sqrt(cc), ws.wo, ws.bo, h)
-        fn = O.outer_attention if mode == "outer" else O.inner_attention
-        t0 = time.time(); fn(x, None, ws, sub, fused); fn(x, ctx, wx, sub, fused); ta = time.time() - t0
-        t0 = time.time(); O.plain_attention(x, None, ws); O.plain_attention(x, ctx, wx); tp = time.time() - t0
-        t_aid += nblk * ta * n_frames / 3.0
-        t_plain += nblk * tp * n_frames / 3.0
+        rn = lambda *sh, sc=1.0: torch.randn(*sh, generator=g) * sc      # noqa: E731
+        x, ctx = rn(n_frames, s, c), rn(n_frames, spec["text_len"], cc)
+        ws = (rn(c, c, sc=c ** -0.5), rn(c, c, sc=c ** -0.5), rn(c, c, sc=c ** -0.5), rn(c, c, sc=c ** -0.5), rn(c, sc=.01))
+        wx = (ws[0], rn(c, cc, sc=cc ** -0.5), rn(c, cc, sc=cc ** -0.5), ws[3], ws[4])
+        ta = timed(lambda: (P.processor_call(x, None, *ws, h, mode, fused, coef), P.processor_call(x, ctx, *wx, h, mode, fused, coef)))
+        tp = timed(lambda: (P.processor_call(x, None, *ws, h, "plain", False, None), P.processor_call(x, ctx, *wx, h, "plain", False, None)))
+        t_aid += nblk * ta
+        t_plain += nblk * tp
     n_aid = int(steps * warmup_ratio)
     total = n_aid * (t_aid + t_plain) + (steps - n_aid) * 2 * t_plain
-    scale50 = 50.0 / steps
-    cores = os.cpu_count() or 1
-    return dict(value=n_frames / (total * scale50), unit="interpolation-frames/sec (50-step)", cores=cores,
-                kind="port",
-                sample=(f"numpy fp32 oracle, 1 transformer block (self+cross call) per resolution level in {early} and "
-                        f"plain mode on the 3-frame sub-batch [first, middle, last]; scaled x{n_frames}/3 frames, x blocks per "
-                        f"level, x({n_aid} AID + {2 * steps - n_aid} plain passes); measured {time.time() - t0_all:.1f} s of CPU work"))
+    return dict(value=n_frames / (total * 50.0 / steps), unit="interpolation-frames/sec (50-step)",
+                cores=torch.get_num_threads(), kind="port",
+                sample=(f"oracle/aid_cpu_port.py (torch CPU ops, fp32, {torch.get_num_threads()} threads of {cores} host cpus): 1 "
+                        f"transformer block (self + cross call) per resolution level in {early} and in plain mode on all "
+                        f"{n_frames} frames ({sum(1 for k in shots if k == 3)} calls median-of-3, {sum(1 for k in shots if k == 1)} single "
+                        f"shot); scaled x blocks per level, x({n_aid} AID + {2 * steps - n_aid} plain passes), x50/{steps}; "
+                        f"measured {time.time() - t0_all:.1f} s of CPU work"))
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # development aid: AID_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0 with gloo collectives, so the N>1 code
-    # path (sharding, broadcast, all_gather, max-over-ranks) can be exercised on a 1-GPU box
-    one_dev = os.environ.get("AID_BENCH_ONE_DEVICE") == "1"
-    dev_index = 0 if one_dev else local_rank
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_dev:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-    if args.gpus != world:
-        if rank == 0:
-            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
-
-    import aid_amd
+# ----------------------------------------------------------------------------------------------------
+def build_workload(name, args, world, rank, device, torch, aid_amd):
+    """Stack + inputs + loop of one workload on this rank.  Returns a dict."""
     from aid_amd import dist as adist
     from aid_amd.loop import AidDenoiseLoop, install_sequence_processors
-    aid_amd._lib.load()                     # fail loudly before anything else if the HIP library is missing
-
-    model = args.model
-    early = args.early or DEFAULT_EARLY[model]
-    dtype = DTYPES[model]
-    n_total = args.frames_per_gpu * world
-    shard = adist.frame_shard(n_total, world, rank)
+    stack, dt, early_default, frames_default, guide_default, what = WORKLOADS[name]
+    dtype = torch.float16 if dt == "f16" else torch.bfloat16
+    early = args.early or early_default
     steps = args.steps
+    if args.frames is not None:
+        n_total = args.frames
+    elif args.weak and world > 1:
+        n_total = args.frames_per_gpu * world
+    else:
+        n_total = frames_default
+    shard = adist.frame_shard(n_total, world, rank)
+    guided = guide_default if args.guide_prompt == "auto" else args.guide_prompt == "on"
+    if name == "ip":
+        guided = False
 
-    unet = aid_amd.AttnStackUNet(model, dtype=dtype, device=device)
+    unet = aid_amd.AttnStackUNet(stack, dtype=dtype, device=device)
     unet.sublayers = args.sublayers
     coef = aid_amd.generate_beta_tensor(n_total, steps, steps)
     coef[0], coef[-1] = 0, 1
-    guided = args.guide_prompt == "on" or (args.guide_prompt == "auto" and model == "sdxl")
     # PAID (gradio ...stable_diffusion.py:221-229): contexts [start, guide x (N-2), end] -> 3 distinct rows
     global_ctx = ([0] + [1] * (n_total - 2) + [2]) if guided else list(range(n_total))
-    xs, cond, uncond = make_inputs(unet, n_total, dtype, device, n_ctx=3 if guided else None)
+    xs, cond, uncond, g = make_inputs(unet, n_total, dtype, device, n_ctx=3 if guided else None)
+    ip_pos = ip_neg = None
+    if name == "ip":
+        # image embeddings after encoder_hid_proj, the reference's layout: 3 copies per frame, [3 N, 1, T, Cc]
+        # (pipeline_interpolated_sd.py:1763-1802); negative image embeddings for the unconditional pass
+        ip_pos = torch.randn(n_total, 1, args.ip_tokens, unet.cross_dim, generator=g).to(dtype).to(device)
+        ip_neg = torch.randn(n_total, 1, args.ip_tokens, unet.cross_dim, generator=g).to(dtype).to(device)
     if world > 1:                            # conditioning comes from rank 0 (north_star: RCCL broadcast)
         named = {f"x{s}_{c}": t for (s, c), t in xs.items()}
         named.update(cond=cond, uncond=uncond)
+        if ip_pos is not None:
+            named.update(ip_pos=ip_pos, ip_neg=ip_neg)
         adist.broadcast_conditioning(named, src=0)
     xs = {k: adist.shard_rows(v, shard) for k, v in xs.items()}
     rows = [global_ctx[f] for f in shard.index]              # context row of every local frame ...
@@ -207,11 +281,28 @@ def main():
     sel = torch.tensor(used, device=device)
     cond, uncond = cond.index_select(0, sel).contiguous(), uncond.index_select(0, sel).contiguous()
     local_coef = coef[list(shard.index)]
-    install_sequence_processors(unet, shard.n_local, early=early, num_inference_steps=steps, coef=local_coef)
-
+    batched = not args.separate_passes
+    if name == "ip":
+        unet.load_ip_adapter(num_tokens=args.ip_tokens, scale=0.6)
+        aid_amd.load_aid_ip_adapter(unet, t=None, size=shard.n_local, is_fused=True, early=early, alpha=steps, beta=steps)
+        for p in unet.attn_processors.values():
+            p.coef = local_coef.detach().to(torch.float32).cpu().clone()
+        rep3 = lambda t: adist.shard_rows(t, shard).repeat_interleave(3, dim=0).contiguous()      # noqa: E731
+        cond, uncond = (cond, [rep3(ip_pos)]), (uncond, [rep3(ip_neg)])
+        batched = False                      # the two passes carry different image embeddings: two UNet calls, like the reference
+    else:
+        install_sequence_processors(unet, shard.n_local, early=early, num_inference_steps=steps, coef=local_coef)
     loop = AidDenoiseLoop(unet, xs, cond, uncond, num_inference_steps=steps, warmup_ratio=args.warmup_ratio,
-                          use_graphs=not args.no_graph, batched_cfg=not args.separate_passes, ctx_index=ctx_index)
-    gather_key = unet.level_shapes()[-1]
+                          use_graphs=not args.no_graph, batched_cfg=batched, ctx_index=ctx_index)
+    return dict(name=name, stack=stack, dtype=dt, early=early, what=what, n_total=n_total, shard=shard, guided=guided,
+                unet=unet, loop=loop, batched=batched, gather_key=unet.level_shapes()[-1])
+
+
+def time_workload(wl, args, world, device, torch, dist):
+    """W untimed warm-up steps, then EXACTLY K steps x `repeats`, bracketed by barrier + synchronize; max over ranks."""
+    from aid_amd import dist as adist
+    loop, steps = wl["loop"], args.steps
+    one_dev = os.environ.get("AID_BENCH_ONE_DEVICE") == "1"
 
     def run_steps(idx):
         out = None
@@ -221,14 +312,24 @@ def main():
 
     # untimed warm-up: alternate AID / plain steps so every graph is captured and warm
     warm_idx = [0 if (j % 2 == 0) else steps - 1 for j in range(max(args.warmup, 2))]
-    run_steps(warm_idx)
+    run_steps(warm_idx[:2])
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(warm_idx[2:] or warm_idx[:2])
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / max(len(warm_idx[2:] or warm_idx[:2]), 1)
+    reps = max(1, int(math.ceil(args.min_seconds / max(est * steps, 1e-6))))
     if world > 1:
+        r = torch.tensor([reps], device="cpu" if one_dev else device, dtype=torch.int64)
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        reps = int(r.item())
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = run_steps(range(steps))
-    final = adist.gather_owned(out[gather_key], shard)          # all_gather of the owned frames' outputs
+    out = None
+    for _ in range(reps):
+        out = run_steps(range(steps))
+    final = adist.gather_owned(out[wl["gather_key"]], wl["shard"])      # all_gather of the owned frames' outputs
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -238,56 +339,98 @@ def main():
         t = torch.tensor([elapsed], device="cpu" if one_dev else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert final.shape[0] == n_total and torch.isfinite(final.float()).all()
+    assert final.shape[0] == wl["n_total"] and torch.isfinite(final.float()).all()
+    ms_per_step = elapsed * 1000.0 / (steps * reps)
+    return dict(ms_per_step=ms_per_step, value=wl["n_total"] / (ms_per_step * 50.0 / 1000.0), repeats=reps,
+                timed_seconds=elapsed, warmup=len(warm_idx))
 
-    ms_per_step = elapsed * 1000.0 / steps
-    value = n_total / (ms_per_step * 50.0 / 1000.0)
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development aid: AID_BENCH_ONE_DEVICE=1 runs all ranks on cuda:0 with gloo collectives, so the N>1 code
+    # path (sharding, broadcast, all_gather, max-over-ranks) can be exercised on a 1-GPU box
+    one_dev = os.environ.get("AID_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_dev else local_rank
+    backend = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if one_dev else "nccl"
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+
+    import aid_amd
+    from aid_amd import dist as adist
+    aid_amd._lib.load()                     # fail loudly before anything else if the HIP library is missing
+
+    name = args.workload
+    if name == "auto":
+        name = args.model or ("sdxl" if world == 1 else "seq16")
+    wl = build_workload(name, args, world, rank, device, torch, aid_amd)
+    tm = time_workload(wl, args, world, device, torch, dist)
+    shard, loop, steps = wl["shard"], wl["loop"], args.steps
 
     result = {
         "metric": "interpolation-frames/sec (50-step)",
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": len(warm_idx),
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
+        "value": tm["value"], "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": tm["warmup"],
+        "ms_per_step": tm["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak" if (args.weak or world == 1) else "strong", "vs_baseline": None,
+        "dtype": wl["dtype"], "data": "synthetic",
+        "repeats": tm["repeats"], "timed_seconds": tm["timed_seconds"],
         "config": {
-            "workload": ("BASELINE configs[1]: SD1.5 512x512 attention stack (32 attention calls / UNet pass)" if model == "sd15"
-                         else "BASELINE configs[2]: SDXL-base 1024x1024 attention stack (140 attention calls / UNet pass)"),
-            "frames": n_total, "frames_per_gpu": args.frames_per_gpu, "local_batch": shard.n_local,
-            "early": early, "late": "plain", "warmup_ratio": args.warmup_ratio,
+            "workload": wl["what"],
+            "frames": wl["n_total"], "local_batch": shard.n_local, "owned_frames": shard.n_owned,
+            "early": wl["early"], "late": "plain", "warmup_ratio": args.warmup_ratio,
             "aid_steps": loop.warmup_steps,
-            "passes_per_step": ("cond + uncond (CFG), two UNet calls" if args.separate_passes
-                                else "cond + uncond (CFG) batched in one UNet call [cond ; uncond]"),
+            "passes_per_step": ("cond + uncond (CFG) batched in one UNet call [cond ; uncond]" if wl["batched"]
+                                else "cond + uncond (CFG), two UNet calls"),
             "contexts": ("PAID guide prompt: interior frames share one text context (3 distinct per pass), keys/values "
-                         "projected once per distinct context" if guided else "one text context per frame"),
+                         "projected once per distinct context" if wl["guided"] else "one text context per frame"),
             "sublayers": {"off": "attention calls only (the BASELINE metric)",
                           "steps": "LayerNorm + call + residual add per layer, three steps (torch LayerNorm / add)",
                           "fused": "LayerNorm + call + residual add per layer in one library call"}[args.sublayers],
             "coef": f"BetaPPF(alpha=beta={steps})", "hipgraph": not args.no_graph,
             "parallelism": f"frame-shard x{world} (replicated end points, no per-layer collective)",
+            "ranks": world, "backend": backend,
+            "expected_speedup_vs_1gpu": adist.expected_speedup(wl["n_total"], world),
         },
     }
+    if name == "ip":
+        result["config"]["ip_adapter"] = (f"{args.ip_tokens} image tokens per frame, image embeddings [3 N, 1, T, Cc]; AID pass = "
+                                          f"{wl['early']} IP processors, other passes = IP-Adapter attention (text + scale x image)")
+    if world > 1:
+        result["config"]["max_local_batch"] = max(adist.frame_shard(wl["n_total"], world, r).n_local for r in range(world))
 
     if rank == 0 and world == 1 and not args.no_roofline:
-        agg = roofline_pass(loop, aid_amd)
-        attn = {k: v for k, v in agg.items()}
-        dom = max(attn, key=lambda k: attn[k]["ms"])
-        d = attn[dom]
-        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        result["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-            "traffic": recorded_traffic(model, dom), "kernel": dom, "launches": d["launches"],
-            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-            "avg_launch_us": d["ms"] * 1e3 / d["launches"], "avg_launch_gflop": d["flops"] / d["launches"] / 1e9,
-            "note": "algorithmic flops (SURVEY.md §8d) / HIP-event time on the launch stream, 1 AID step + 1 plain step",
-            "kernels": {k: {"ms": round(v["ms"], 4), "launches": v["launches"],
-                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
-                            "min_bytes_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in sorted(agg.items())},
-        }
-        tot_ms = sum(v["ms"] for v in agg.values())
-        tot_fl = sum(v["flops"] for v in agg.values())
-        result["roofline"]["stack_tflops"] = tot_fl / (tot_ms * 1e-3) / 1e12
-        result["roofline"]["kernel_ms_per_2steps"] = tot_ms
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(model, n_total, early, steps, args.warmup_ratio)
+        result["roofline"] = roofline_object(roofline_pass(loop, aid_amd, torch), wl["stack"])
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and name != "ip":
+        result["cpu_baseline"] = cpu_baseline(wl["stack"], wl["n_total"], wl["early"], steps, args.warmup_ratio)
+    if rank == 0 and world == 1 and name == "sdxl" and args.workload == "auto" and not args.model and not args.no_also:
+        # BASELINE's metric names SD1.5 512^2 AND SDXL 1024^2: the SD1.5 half rides along (same steps / repeats rule)
+        del wl, loop
+        torch.cuda.empty_cache()
+        w2 = build_workload("sd15", args, world, rank, device, torch, aid_amd)
+        t2 = time_workload(w2, args, world, device, torch, dist)
+        also = {"workload": w2["what"], "value": t2["value"], "unit": "frames/s", "ms_per_step": t2["ms_per_step"],
+                "repeats": t2["repeats"], "dtype": w2["dtype"], "early": w2["early"], "frames": w2["n_total"]}
+        if not args.no_roofline:
+            r2 = roofline_object(roofline_pass(w2["loop"], aid_amd, torch), "sd15")
+            also["roofline"] = {k: r2[k] for k in ("kernel", "achieved", "frac", "achieved_executed", "frac_executed",
+                                                   "traffic", "avg_launch_us", "share_of_kernel_time", "stack_tflops", "kernels")}
+        result["also"] = {"sd15": also}
 
     if rank == 0:
         print(json.dumps(result))

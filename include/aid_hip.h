@@ -15,8 +15,12 @@
  *                             OuterInterpolatedAttnProcessor   interpolation.py:573-679
  *                             InnerInterpolatedAttnProcessor   interpolation.py:707-804
  *                             de-activated fallback (AttnProcessor2_0)  interpolation.py:581-584
- *                             IP variants are composed from two calls of aid_attn_fwd
- *                             (interpolation.py:240-387, 417-545, 76-211)
+ *                             IP-Adapter variants (image branch = the ip_* fields):
+ *                             OuterInterpolatedIPAttnProcessor  interpolation.py:240-387
+ *                             InnerInterpolatedIPAttnProcessor  interpolation.py:417-545
+ *                             ScaleControlIPAttnProcessor       interpolation.py:76-211
+ *                             de-activated IP fallback (diffusers IPAdapterAttnProcessor2_0, called at
+ *                             interpolation.py:248-251 / 425-428; semantics SURVEY.md App. A)
  *   aid_gemm_nt            <- attn.to_q / to_k / to_v / to_out[0]   interpolation.py:613,623-624,666
  *   aid_attn_fwd           <- end-point select / replicate / concat / get_attention_scores /
  *                             bmm / batch_to_head_dim / outer|inner lerp
@@ -32,11 +36,16 @@
 extern "C" {
 #endif
 
-#define AID_ABI_VERSION 2
+#define AID_ABI_VERSION 3
 
 /* element types of activations / weights (accumulation is always fp32) */
 #define AID_DTYPE_F16  0
 #define AID_DTYPE_BF16 1
+
+/* image branch of the IP-Adapter processors (AidProcessorArgs.ip_mode) */
+#define AID_IP_NONE       0
+#define AID_IP_SAME       1
+#define AID_IP_PLAIN      2
 
 /* attention modes */
 #define AID_MODE_PLAIN 0   /* softmax(Q K_i^T) V_i                       (AID de-activated)          */
@@ -64,7 +73,7 @@ extern "C" {
  *   Requirements: k % 8 == 0, lda % 8 == 0, ldb % 8 == 0, ldc % 4 == 0, ldc >= round_up(n, 4),
  *   all base pointers 16-byte aligned.  Columns [n, round_up(n,4)) of C are written with zeros.
  * ------------------------------------------------------------------------------------- */
-#define AID_GEMM_MAX_PROBLEMS 4
+#define AID_GEMM_MAX_PROBLEMS 6
 
 typedef struct AidGemmProblem {
     const void* a;
@@ -136,6 +145,10 @@ typedef struct AidAttnArgs {
     int32_t n_plain;             /* frames with a negative coefficient (profiling accounting) */
     int32_t q_prescaled;         /* 1: q already holds q * softmax_scale * log2(e) (fold it into the     */
                                  /* q-projection via AidGemmProblem.scale); 0: the kernel scales Q itself */
+    int32_t seg_executed;        /* profiling accounting: (frame, key segment) passes this launch really runs —  */
+                                 /* fused END-POINT frames and coefficient-0/1 sides run fewer than the          */
+                                 /* algorithmic count; 0 = unknown (reported equal to the algorithmic count)     */
+    int32_t reserved0;
 } AidAttnArgs;
 
 int aid_attn_fwd(const AidAttnArgs* args /* host */, void* stream);
@@ -154,8 +167,8 @@ int aid_lerp_kv(const void* k, const void* vt, void* k2, void* vt2, const float*
  *   x   [n_frames, s, c]   hidden states          ctx [n_frames, l, cc] or NULL (self-attn: ctx = x)
  *   wq [c, c]  wk [c, cc]  wv [c, cc]  wo [c, c]  bo [c]      (torch Linear.weight layout [out, in])
  *   y   [n_frames, s, c]   = to_out( AID-attention( to_q(x), to_k(ctx), to_v(ctx) ) )
- * Launches: [1 LayerNorm,] 1 grouped GEMM (q, k, V^T), [INNER: 1 streaming K/V lerp,] 1 attention kernel,
- * 1 GEMM (out-proj + bias [+ residual]).
+ * Launches: [1 LayerNorm,] 1 grouped GEMM (q, k, V^T [, K_ip, V_ip^T]), [INNER: 1 streaming K/V lerp,] 1 attention
+ * kernel [+ 1 for the image branch, accumulating], 1 GEMM (out-proj + bias [+ residual]).
  * Optional block-level fusion: with ln_eps > 0 the call computes on LayerNorm(x) (the block's
  * norm1 / norm2; self-attention keys / values use the normalised x too, a cross-attention ctx is left alone), and
  * with `residual` it returns  residual + to_out(...)  — together  h + attn(norm(h))  in one call.
@@ -186,6 +199,28 @@ typedef struct AidProcessorArgs {
     const void* ln_gamma;        /* [c] or NULL                                               */
     const void* ln_beta;         /* [c] or NULL                                               */
     const void* residual;        /* [n_frames, s, c] or NULL: added to y (may alias x)        */
+    /* ---- IP-Adapter image branch (ip == NULL: none).  Image tokens: n_ip rows of [t_ip, cc] (cc = the text   */
+    /* context width), row r at ip + r * ip_stride elements (a strided view such as ip_hidden_states[0][::3]    */
+    /* needs no copy).  K_ip = to_k_ip(ip), V_ip = to_v_ip(ip) are projected in the same grouped launch as      */
+    /* q / k / V^T; frame i uses image row ip_map[i] (NULL = identity, then n_ip == number of AID frames).      */
+    /*   AID_IP_SAME       O += ip_scale * [the text mode's interpolation scheme on the image keys]             */
+    /*                     (OUTER only: interpolation.py:329-367, outputs are lerped AFTER the sum)             */
+    /*   AID_IP_PLAIN      O += ip_scale * A(Q_i, K_ip[row i], V_ip[row i])      (interpolation.py:525-530;     */
+    /*                     de-activated IPAdapterAttnProcessor2_0 with the [9,1,T,Cc] fold as t_ip = 3 T)       */
+    /* ip_frame_scale (device [n_frames] or NULL) multiplies ip_scale per frame: ScaleControlIPAttnProcessor's     */
+    /* `coef * ip_hidden_states` (interpolation.py:146-150, 196) is AID_IP_PLAIN with ip_frame_scale = coef.       */
+    const void*    ip;
+    const void*    wk_ip;        /* [c, cc] */
+    const void*    wv_ip;        /* [c, cc] */
+    const int32_t* ip_map;       /* device [n_frames] or NULL */
+    const float*   ip_frame_scale; /* device [n_frames] or NULL */
+    int64_t ip_stride;           /* elements between consecutive image rows (>= t_ip * cc, multiple of 8) */
+    int32_t n_ip, t_ip;
+    int32_t ip_mode;             /* AID_IP_*                                                  */
+    float   ip_scale;
+    int32_t ip_begin, ip_end;    /* AID_IP_SAME: image rows of the end-point frames           */
+    int32_t seg_executed;        /* accounting, see AidAttnArgs.seg_executed (text launch only) */
+    int32_t reserved0;
 } AidProcessorArgs;
 
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args /* host */);
@@ -201,10 +236,12 @@ int    aid_processor_fwd(const AidProcessorArgs* args /* host */, void* stream);
  * outer 3; bytes: operands read once + result written once).  Not for use inside stream capture.
  * ------------------------------------------------------------------------------------- */
 typedef struct AidProfileEntry {
-    char   kernel[64];     /* variant name, e.g. "aid_attn<f16,d40,inner,nw4>" or "aid_gemm_nt<f16>" */
+    char   kernel[64];     /* kernel that ran: "aid_attn<f16,d40,inner,nw4>", "aid_gemm_nt_pp_kernel<bf16>", ... */
     double ms;
-    double flops;
+    double flops;          /* algorithmic                                                      */
     double bytes;
+    double flops_executed; /* what the launch really computes: attention with the executed segment count      */
+                           /* (AidAttnArgs.seg_executed), GEMM = algorithmic                                  */
 } AidProfileEntry;
 
 int aid_profile_begin(void);

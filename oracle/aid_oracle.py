@@ -31,7 +31,7 @@ __all__ = [
     "AttnWeights", "IPWeights", "beta_coefs", "coef_for_t",
     "linear", "split_heads", "merge_heads", "softmax_attention",
     "plain_attention", "outer_attention", "inner_attention",
-    "outer_ip_attention", "inner_ip_attention", "scale_control_ip_attention",
+    "outer_ip_attention", "inner_ip_attention", "scale_control_ip_attention", "ip_adapter_attention",
     "attn_core", "slerp", "linear_interpolation", "spherical_interpolation",
     "next_exploration_t",
     "layer_norm",
@@ -229,7 +229,9 @@ def inner_attention(x, ctx, w: AttnWeights, coef, is_fused: bool) -> np.ndarray:
     return _out(attn_core(q, k, v, w.heads, w.scale, "inner", is_fused, coef), w)
 
 
-# ---- IP-Adapter variants (batch hard-wired to 3) --------
+# ---- IP-Adapter variants.  The reference hard-wires a batch of 3: ``expand(3, ...)``, ``[::3]``,
+# ``[6:9]`` on a [9, 1, T, Cc] image-embedding tensor.  Restated for N = x.shape[0] frames and r = R / N copies per
+# frame (``[::r]``, rows of the last frame); for N = 3, R = 9 this IS the reference's arithmetic (pinned by the goldens).
 def _ip_kv(ip_rows: np.ndarray, ipw: IPWeights):
     """to_k_ip[0] / to_v_ip[0] on [3, 1, T, Cc] rows -> [3, T, C] (the 4-D
     head_to_batch_dim fold, interpolation.py:330-341)."""
@@ -248,7 +250,7 @@ def outer_ip_attention(x, text, ip, w: AttnWeights, ipw: IPWeights, coef, is_fus
     qh = split_heads(q, w.heads)
 
     def two_sided(k_, v_):
-        n = 3                                            # literal 3, interpolation.py:300-303
+        n = x.shape[0]                                   # literal 3 in the reference, interpolation.py:300-303
         kbh, keh = split_heads(_rep(k_, 0, n), w.heads), split_heads(_rep(k_, -1 % k_.shape[0], n), w.heads)
         vbh, veh = split_heads(_rep(v_, 0, n), w.heads), split_heads(_rep(v_, -1 % v_.shape[0], n), w.heads)
         if is_fused:
@@ -261,7 +263,7 @@ def outer_ip_attention(x, text, ip, w: AttnWeights, ipw: IPWeights, coef, is_fus
 
     o_b, o_e = two_sided(k, v)
     if ip is not None:
-        kip, vip = _ip_kv(ip[::3], ipw)                 # interpolation.py:330-331
+        kip, vip = _ip_kv(ip[::ip.shape[0] // x.shape[0]], ipw)     # [::3], interpolation.py:330-331
         ip_b, ip_e = two_sided(kip, vip)
         s = dt.type(ipw.scale)
         o_b = o_b + s * ip_b                            # interpolation.py:364-367
@@ -280,9 +282,24 @@ def inner_ip_attention(x, text, ip, w: AttnWeights, ipw: IPWeights, coef, is_fus
         if not is_fused:
             raise RuntimeError("inner IP branch is shape-invalid without is_fused "
                                "(reference: bmm shape mismatch, interpolation.py:525)")
-        kip, vip = _ip_kv(ip[::3], ipw)                 # interpolation.py:502-505
+        kip, vip = _ip_kv(ip[::ip.shape[0] // x.shape[0]], ipw)     # [::3], interpolation.py:502-505
         o_ip = attn_core(q, kip, vip, w.heads, w.scale, "plain", False, None)
         o = o + x.dtype.type(ipw.scale) * o_ip          # interpolation.py:530
+    return _out(o, w)
+
+
+def ip_adapter_attention(x, text, ip, w: AttnWeights, ipw: IPWeights):
+    """What the de-activated Outer / Inner IP processors compute: they return ``self.ip_attn(...)``
+    (interpolation.py:248-251, 425-428), diffusers' IPAdapterAttnProcessor2_0 (third-party):
+    plain text attention + scale[0] x plain attention over the image tokens, the [R, 1, T, Cc] tensor folded into
+    the batch by ``view(batch, -1, heads, head_dim)`` (frame i gets the tokens of rows [i R/B, (i+1) R/B))."""
+    q, k, v = _project(x, text, w)
+    o = attn_core(q, k, v, w.heads, w.scale, "plain", False, None)
+    if ip is not None:
+        b = x.shape[0]
+        kip = linear(ip, ipw.wk_ip).reshape(b, -1, q.shape[-1])
+        vip = linear(ip, ipw.wv_ip).reshape(b, -1, q.shape[-1])
+        o = o + x.dtype.type(ipw.scale) * attn_core(q, kip, vip, w.heads, w.scale, "plain", False, None)
     return _out(o, w)
 
 
@@ -297,7 +314,9 @@ def scale_control_ip_attention(x, text, ip, w: AttnWeights, ipw: IPWeights, coef
     else:
         o = attn_core(q, k, v, w.heads, w.scale, "plain", False, None)      # :130-135
     if ip is not None:
-        kip, vip = _ip_kv(ip[6:9], ipw)                 # :137-138 / :187-188
+        n, r = x.shape[0], ip.shape[0] // x.shape[0]
+        last = ip[r * (n - 1):] if r == n else np.repeat(ip[r * (n - 1): r * (n - 1) + 1], n, axis=0)
+        kip, vip = _ip_kv(last, ipw)                    # [6:9] (the END frame's rows), :137-138 / :187-188
         o_ip = attn_core(q, kip, vip, w.heads, w.scale, "plain", False, None)
         o = o + _cvec(coef, x.dtype) * o_ip             # :146-150 / :196
     return _out(o, w)

@@ -41,7 +41,7 @@ class TextCase:
 @dataclass(frozen=True)
 class IPCase:
     name: str
-    kind: str         # outer_ip | inner_ip | scale_control | scale_control_off
+    kind: str         # outer_ip | inner_ip | scale_control | scale_control_off | outer_ip_off | inner_ip_off
     is_fused: bool
     tokens: int       # T image tokens
     s: int = 24
@@ -94,6 +94,13 @@ def _ip_cases() -> List[IPCase]:
                             ("scale_control_off", True)):
             sd += 1
             cases.append(IPCase(f"ip{tokens}_{kind}_{'fused' if fused else 'pure'}", kind, fused, tokens, seed=sd))
+    # de-activated outer / inner IP processors: the reference hands the call to its wrapped ``ip_attn``
+    # (interpolation.py:248-251, 425-428) = diffusers' IPAdapterAttnProcessor2_0 (restated by the generator, App. A)
+    sd = 400
+    for tokens in (4, 16):
+        for kind in ("outer_ip_off", "inner_ip_off"):
+            sd += 1
+            cases.append(IPCase(f"ip{tokens}_{kind}", kind, True, tokens, seed=sd))
     return cases
 
 

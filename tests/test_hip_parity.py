@@ -277,9 +277,13 @@ def test_ip_processors_vs_reference_goldens(case, dtype):
         ipa.to_v_ip[0].weight.copy_(torch.from_numpy(inp["wv_ip"]).to(dtype))
     cls = {"outer_ip": aid_amd.OuterInterpolatedIPAttnProcessor, "inner_ip": aid_amd.InnerInterpolatedIPAttnProcessor,
            "scale_control": aid_amd.ScaleControlIPAttnProcessor,
-           "scale_control_off": aid_amd.ScaleControlIPAttnProcessor}[case.kind]
+           "scale_control_off": aid_amd.ScaleControlIPAttnProcessor,
+           "outer_ip_off": aid_amd.OuterInterpolatedIPAttnProcessor,
+           "inner_ip_off": aid_amd.InnerInterpolatedIPAttnProcessor}[case.kind]
+    if case.kind in ("outer_ip_off", "inner_ip_off"):          # what load_aid_ip_adapter installs as the fallback
+        ipa = aid_amd.HipIPAdapterAttnProcessor.wrap(ipa)
     proc = cls(t=case.t, is_fused=case.is_fused, ip_attn=ipa)
-    if case.kind == "scale_control_off":
+    if case.kind.endswith("_off"):
         proc.deactivate()
     ehs = (torch.from_numpy(inp["text"]).to(dtype).to(DEV), [torch.from_numpy(inp["ip"]).to(dtype).to(DEV)])
     y = proc(attn, torch.from_numpy(inp["x"]).to(dtype).to(DEV), encoder_hidden_states=ehs)
@@ -413,15 +417,22 @@ BENCH_LAYERS = [  # (model, dtype, S, C, heads, text width, mode, fused): every 
 ]
 
 
+# BASELINE configs[3]: 16 frames over 8 GPUs -> an interior rank runs the local batch [frame 0, 2 owned, frame 15] = 4 frames
+# whose coefficients are rows of the 16-frame schedule (dist.frame_shard); same call structure as above
+SHARD_LAYERS = [l_ + (4,) for l_ in BENCH_LAYERS if l_[0] == "sdxl"]
+
+
 @pytest.mark.parametrize("cross", [False, True], ids=["self", "cross"])
-@pytest.mark.parametrize("layer", BENCH_LAYERS, ids=lambda t: f"{t[0]}_s{t[2]}_c{t[3]}")
+@pytest.mark.parametrize("layer", [l_ + (7,) for l_ in BENCH_LAYERS] + SHARD_LAYERS,
+                         ids=lambda t: f"{t[0]}_s{t[2]}_c{t[3]}_n{t[8]}")
 def test_every_bench_layer_at_full_size_vs_oracle(layer, cross):
-    """The exact calls bench.py times — 7 AID frames + 7 plain rider frames in one call, BetaPPF(50, 50) coefficients,
+    """The exact calls bench.py times — n AID frames + n plain rider frames in one call, BetaPPF(50, 50) coefficients,
     SDXL cross-attention with the PAID shared contexts — against the fp64 oracle on sampled query rows of the begin,
     an interior and the end frame and of one rider frame.  (Whatever GEMM engine / attention variant the library
-    picks for these shapes is what gets checked.)"""
-    model, dtype, s, c, heads, cc, mode, fused = layer
-    n, l = 7, 77
+    picks for these shapes is what gets checked.)  n = 7: configs[1] / configs[2]; n = 4: the per-rank batch of
+    configs[3] (2 owned frames + the 2 replicated end points, coefficient rows [0, 7, 8, 15] of the 16-frame schedule)."""
+    model, dtype, s, c, heads, cc, mode, fused, n = layer
+    l = 77
     g = torch.Generator().manual_seed(s + c + int(cross))
     attn = aid_amd.AttnShim(c, heads, cc if cross else None, dtype=dtype, device=DEV)
     x = torch.randn(2 * n, s, c, generator=g).to(dtype)
@@ -431,6 +442,11 @@ def test_every_bench_layer_at_full_size_vs_oracle(layer, cross):
     ctxd = torch.randn(max(idx2) + 1, l, cc, generator=g).to(dtype) if cross else None     # distinct contexts
     cls = aid_amd.OuterInterpolatedAttnProcessor if mode == "outer" else aid_amd.InnerInterpolatedAttnProcessor
     proc = cls(size=n, is_fused=fused, alpha=50, beta=50)
+    if n == 4:
+        from aid_amd.dist import frame_shard
+        sh = frame_shard(16, 8, 3)
+        assert sh.index == (0, 6, 7, 15) and sh.owned_local == (1, 3)
+        proc.coef = torch.from_numpy(O.beta_coefs(16, 50, 50))[list(sh.index)].clone()
     proc.plain_tail = n
     y = proc(attn, x.to(DEV), encoder_hidden_states=None if ctxd is None else ctxd.to(DEV),
              **({"ctx_index": idx2} if shared else {}))
@@ -445,7 +461,7 @@ def test_every_bench_layer_at_full_size_vs_oracle(layer, cross):
         q, k, v = O._project(xs, cs, w)
         return O._out(O.attn_core(q[:, rows], k, v, heads, w.scale, md, fused and md != "plain", cf), w)
 
-    sel = [0, 3, n - 1]
+    sel = [0, n // 2, n - 1]
     assert rel_l2(to_np64(y[sel][:, rows]), oracle(sel, mode, coef[sel])) < TOL[dtype]
     assert rel_l2(to_np64(y[n + 2:n + 3][:, rows]), oracle([n + 2], "plain", None)) < TOL[dtype]
 
@@ -679,12 +695,13 @@ def test_randomized_shapes_all_modes():
         assert err < TOL[dtype], (it, d, h, n, s, l, mode, fused, begin, end, err)
 
 
+@pytest.mark.parametrize("shape", [(1024, 1280, 20), (4096, 640, 10)], ids=["s1024_c1280", "s4096_c640"])
 @pytest.mark.parametrize("tokens", [4, 16])
-def test_ip_processors_at_sdxl_layer_shape(tokens):
-    """BASELINE configs[4] layer shape (SDXL S=1024, C=1280, H=20, Cc=2048, bf16), batch 3 = the per-rank
-    batch of the 8-frame / 8-GPU layout: outer-IP and scale-control vs the fp64 oracle."""
+def test_ip_processors_at_sdxl_layer_shape(tokens, shape):
+    """BASELINE configs[4] layer shapes (SDXL S=1024/C=1280/H=20 and S=4096/C=640/H=10, Cc=2048, bf16), batch 3 = the
+    per-rank batch of the 8-frame / 8-GPU layout: outer-IP, scale-control and the de-activated fallback vs the fp64 oracle."""
     dtype = torch.bfloat16
-    s, c, h, cc, l = 1024, 1280, 20, 2048, 77
+    (s, c, h), cc, l = shape, 2048, 77
     g = torch.Generator().manual_seed(5)
     mk = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(dtype)   # noqa: E731
     inp = dict(x=mk(3, s, c), text=mk(3, l, cc), ip=mk(9, 1, tokens, cc), wq=mk(c, c, sc=c ** -0.5),
@@ -708,3 +725,44 @@ def test_ip_processors_at_sdxl_layer_shape(tokens):
     y2 = aid_amd.ScaleControlIPAttnProcessor(t=0.4, is_fused=True, ip_attn=ipa)(attn, inp["x"].to(DEV), encoder_hidden_states=ehs)
     ref2 = O.scale_control_ip_attention(n64["x"], n64["text"], n64["ip"], w, ipw, coef, True, activated=True)
     assert rel_l2(to_np64(y2), ref2) < TOL[dtype]
+    off = aid_amd.OuterInterpolatedIPAttnProcessor(t=0.4, is_fused=True, ip_attn=ipa)
+    off.deactivate()                                  # bare weight holder -> HipIPAdapterAttnProcessor on its weights
+    y3 = off(attn, inp["x"].to(DEV), encoder_hidden_states=ehs)
+    assert rel_l2(to_np64(y3), O.ip_adapter_attention(n64["x"], n64["text"], n64["ip"], w, ipw)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("n,r", [(5, 3), (8, 1), (4, 4)])
+def test_ip_processors_n_frame_generalisation(dtype, n, r):
+    """N-frame IP processors (one image-embedding row group per frame; the reference hard-wires 3):
+    N frames, r copies per frame, every variant + the de-activated fallback vs the oracle restated for N frames."""
+    case = C.IPCase("gen", "outer_ip", True, 4, seed=900 + n)
+    rs = np.random.RandomState(case.seed)
+    c, cc = case.c, case.cc
+    inp = dict(x=C.randn(rs, n, case.s, c), text=C.randn(rs, n, case.l, cc), ip=C.randn(rs, n * r, 1, case.tokens, cc),
+               wq=C.randn(rs, c, c, scale=c ** -0.5), wk=C.randn(rs, c, cc, scale=cc ** -0.5),
+               wv=C.randn(rs, c, cc, scale=cc ** -0.5), wo=C.randn(rs, c, c, scale=c ** -0.5), bo=C.randn(rs, c, scale=0.01),
+               wk_ip=C.randn(rs, c, cc, scale=cc ** -0.5), wv_ip=C.randn(rs, c, cc, scale=cc ** -0.5))
+    attn = make_attn(aid_amd, inp, case.heads, cc, dtype, DEV)
+    ipa = aid_amd.IPAdapterShim(c, cc, num_tokens=case.tokens, scale=case.ip_scale, dtype=dtype, device=DEV)
+    with torch.no_grad():
+        ipa.to_k_ip[0].weight.copy_(torch.from_numpy(inp["wk_ip"]).to(dtype))
+        ipa.to_v_ip[0].weight.copy_(torch.from_numpy(inp["wv_ip"]).to(dtype))
+    rd = rounded(inp, dtype)
+    w = O.AttnWeights(rd["wq"], rd["wk"], rd["wv"], rd["wo"], rd["bo"], case.heads)
+    ipw = O.IPWeights(rd["wk_ip"], rd["wv_ip"], case.ip_scale, case.tokens)
+    ehs = (torch.from_numpy(inp["text"]).to(dtype).to(DEV), [torch.from_numpy(inp["ip"]).to(dtype).to(DEV)])
+    x = torch.from_numpy(inp["x"]).to(dtype).to(DEV)
+    for cls, fn in ((aid_amd.OuterInterpolatedIPAttnProcessor, O.outer_ip_attention),
+                    (aid_amd.InnerInterpolatedIPAttnProcessor, O.inner_ip_attention),
+                    (aid_amd.ScaleControlIPAttnProcessor, O.scale_control_ip_attention)):
+        proc = cls(size=n, is_fused=True, alpha=3, beta=3, ip_attn=ipa)
+        coef = proc.coef.to(dtype).float().numpy()
+        y = proc(attn, x, encoder_hidden_states=ehs)
+        assert rel_l2(to_np64(y), fn(rd["x"], rd["text"], rd["ip"], w, ipw, coef, True)) < TOL[dtype], cls.__name__
+    off = aid_amd.InnerInterpolatedIPAttnProcessor(size=n, is_fused=True, ip_attn=ipa)
+    off.deactivate()
+    assert rel_l2(to_np64(off(attn, x, encoder_hidden_states=ehs)),
+                  O.ip_adapter_attention(rd["x"], rd["text"], rd["ip"], w, ipw)) < TOL[dtype]
+    with pytest.raises(RuntimeError, match="frames"):
+        aid_amd.OuterInterpolatedIPAttnProcessor(size=n + 1, is_fused=True, ip_attn=ipa)(attn, x, encoder_hidden_states=ehs)

@@ -3,12 +3,12 @@ import numpy as np
 import torch
 
 # Tolerances (relative L2 over the whole output tensor, HIP path vs the fp64-evaluated oracle on the
-# SAME dtype-rounded inputs).  north_star asks for 1e-3 rel-L2 on fp16 latents; one layer call in
-# fp16 measures <= 8e-4 (inputs, q/k/v, P and the output are each rounded to fp16 once; accumulation
-# is fp32).  bf16 has 3 fewer mantissa bits (eps 3.9e-3 vs 4.9e-4), the same pipeline measures <= 6e-3.
-TOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
-# GEMM alone: one output rounding
-TOL_GEMM = {torch.float16: 6e-4, torch.bfloat16: 4e-3}
+# SAME dtype-rounded inputs).  north_star asks for 1e-3 rel-L2 on fp16 latents: that IS the fp16 bound here (one layer
+# call measures <= 8e-4: inputs, q/k/v, P and the output are each rounded to fp16 once; accumulation is fp32).  bf16
+# has 3 fewer mantissa bits (eps 3.9e-3 vs 4.9e-4); the same pipeline measures <= 6e-3, bound 8e-3.
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+# GEMM alone: one output rounding (measured <= 3e-4 / 2.3e-3)
+TOL_GEMM = {torch.float16: 4e-4, torch.bfloat16: 3e-3}
 
 
 def rel_l2(a, b) -> float:
