@@ -9,7 +9,7 @@ Layout:  csrc/ (HIP kernels + C ABI, built to libaid_hip.so)  ·  _lib.py (ctype
 ops.py (tensor-level entry points)  ·  processors.py (the reference's AttnProcessor classes)  ·
 interp.py (coefficients, slerp / lerp initialisation)  ·  attn_shim.py (diffusers stand-ins)  ·
 dist.py (frame sharding over RCCL)  ·  loop.py (denoising-loop harness)  ·  sequence.py (batch assembly of
-interpolate_single / N-frame interpolate)  ·  prior.py (Beta-prior exploration of the coefficient path).
+interpolate_single / N-frame interpolate)  ·  pipelines.py (the reference's pipeline classes over components)  ·  prior.py (Beta-prior exploration of the coefficient path).
 """
 from .interp import generate_beta_tensor, linear_interpolation, slerp, spherical_interpolation
 from .processors import (HipAttnProcessor, HipIPAdapterAttnProcessor, InnerInterpolatedAttnProcessor,
@@ -17,7 +17,9 @@ from .processors import (HipAttnProcessor, HipIPAdapterAttnProcessor, InnerInter
                          OuterInterpolatedIPAttnProcessor, ScaleControlIPAttnProcessor, activate_aid,
                          deactivate_aid, load_aid, load_aid_ip_adapter)
 from .attn_shim import AttnShim, AttnStackUNet, IPAdapterShim
-from . import ops, _lib, sequence, loop, dist, prior
+from . import ops, _lib, sequence, loop, dist, prior, pipelines
+from .pipelines import (DDIMSchedulerLite, InterpolationStableDiffusionPipeline,
+                        InterpolationStableDiffusionXLPipeline, StackDenoiser)
 
 __all__ = [
     "generate_beta_tensor", "linear_interpolation", "slerp", "spherical_interpolation",
@@ -25,5 +27,6 @@ __all__ = [
     "OuterInterpolatedIPAttnProcessor", "InnerInterpolatedIPAttnProcessor", "ScaleControlIPAttnProcessor",
     "HipAttnProcessor", "HipIPAdapterAttnProcessor", "load_aid", "load_aid_ip_adapter", "activate_aid", "deactivate_aid",
     "AttnShim", "AttnStackUNet", "IPAdapterShim", "ops",
+    "InterpolationStableDiffusionPipeline", "InterpolationStableDiffusionXLPipeline", "DDIMSchedulerLite", "StackDenoiser",
 ]
 __version__ = "0.1.0"

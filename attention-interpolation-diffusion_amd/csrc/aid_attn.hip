@@ -68,13 +68,13 @@ __host__ __device__ constexpr bool attn_prefetch(int d, int nw) { return nw == 4
 
 // Online-softmax state of one wave: reference m (scaled log2 domain, per query = per lane), O^T blocks, and —
 // when the head dim leaves no spare padded row — the extra block whose row 0 accumulates the row sums.
-template <int NDB, bool XL>
+template <int NDB, bool XL, int QB>
 struct OState {
-    float  m;
+    float  m[QB];
     bool   fresh;                       // no tile processed yet: the first tile sets the reference
-    f32x16 o[NDB];
-    f32x16 ol[XL ? 1 : 1];              // only used when XL
-    f32x16 cn;                          // -m in all 16 registers (C operand of the first MFMA), kept when PERSIST_C
+    f32x16 o[QB][NDB];
+    f32x16 ol[QB];                      // only used when XL
+    f32x16 cn[QB];                      // -m in all 16 registers (C operand of the first MFMA), kept when PERSIST_C
 };
 
 typedef __amdgpu_buffer_rsrc_t Rsrc;
@@ -89,7 +89,10 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-template <typename T, int D, int MODE, int NW>
+// QB = 32-row query blocks per wave.  QB = 2 (64 query rows per wave): every K / V^T fragment read from LDS and every
+// staging pass / barrier serves twice the MFMAs, and the two blocks' independent MFMA chains give the scheduler
+// something to put between dependent instructions — at the price of one wave per SIMD (> 256 VGPRs).
+template <typename T, int D, int MODE, int NW, int QB>
 __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) {
     typedef typename Vec<T>::v8 T8;
     typedef typename Vec<T>::v4 T4;
@@ -104,13 +107,13 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     constexpr int NVC = (VCH + NT - 1) / NT;    // Vt chunks per thread per tile
     // Prefetch (issue tile t+1's loads before tile t's compute, two LDS buffers) only where the staging
     // registers fit beside the accumulators; otherwise stage synchronously through one buffer.
-    constexpr bool PREFETCH = attn_prefetch(D, NW);
+    constexpr bool PREFETCH = attn_prefetch(D, NW) || QB > 1;
     constexpr int NBUF = PREFETCH ? 2 : 1;
     // row of ones in V^T -> the row sums l come out of the second MFMA as a row of O^T.  A spare padded row
     // (index D) exists for d = 40 / 80; d = 64 / 160 use one eXtra 32-row block fed from a constant fragment.
     constexpr bool XL = (D == DV);
     constexpr bool KPIPE = true;                // K fragment reads two k-steps ahead of their MFMAs (see tile())
-    constexpr bool PERSIST_C = D <= 64 && !(KPIPE && D == 64 && MODE == AID_MODE_PLAIN);   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
+    constexpr bool PERSIST_C = QB > 1 || (D <= 64 && !(KPIPE && D == 64 && MODE == AID_MODE_PLAIN));   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
     constexpr int LBLK = D / 32, LREG = ((D % 32) / 8) * 4;     // (block, register) of row D at lanes hi == 0
     static_assert(XL || ((D % 32) % 8 == 0 && (D % 32) < 32), "spare row must sit at a register boundary");
     // head-room (log2) of P = 2^x in the storage type before the row reference has to be raised
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const int qb = lid % p.nqb;
     const int fr = (lid / p.nqb) % a.n_frames;
     const int h = lid / (p.nqb * a.n_frames);
-    const int q0 = (qb * NW + wave) * 32;
+    const int q0 = (qb * NW + wave) * 32 * QB;
 
     // zero both LDS buffers once where the head dim is padded (d = 40 / 80): pad columns of K / pad rows of V^T are
     // never staged and must be finite.  d = 64 / 160 have no padding that a fragment read touches.
@@ -144,19 +147,20 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     }
 
     // ---- Q fragments (B operand of the swapped product), straight from global -------------
-    T8 qf[NQK];
-    {
-        const int qr = min(q0 + l31, a.s - 1);           // rows past the end are clamped, never stored
+    T8 qf[QB][NQK];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const int qr = min(q0 + 32 * j + l31, a.s - 1);  // rows past the end are clamped, never stored
         const T* qrow = reinterpret_cast<const T*>(a.q) + (int64_t)fr * a.q_fs + (int64_t)qr * a.ldq + h * D;
 #pragma unroll
         for (int ks = 0; ks < NQK; ++ks) {
             const int col = ks * 16 + hi * 8;
-            qf[ks] = (col < D) ? *reinterpret_cast<const T8*>(qrow + col) : zero8<T>();
+            qf[j][ks] = (col < D) ? *reinterpret_cast<const T8*>(qrow + col) : zero8<T>();
             if (!a.q_prescaled) {                       // generic callers: fold softmax_scale*log2(e) into Q here (one
-                f32x8 t = up8<T>(qf[ks]);               // extra rounding; the processor path does it in the GEMM epilogue)
+                f32x8 t = up8<T>(qf[j][ks]);            // extra rounding; the processor path does it in the GEMM epilogue)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] *= p.c2;
-                qf[ks] = cvt8<T>(t);
+                qf[j][ks] = cvt8<T>(t);
             }
         }
     }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 
     // ---- one segment of keys: online-softmax update of `st` ----------------------------------
     // k0/v0: frame base pointers (already offset to head h)
-    auto run = [&](OState<NDB, XL>& st, const T* k0, const T* v0) __attribute__((always_inline)) {
+    auto run = [&](OState<NDB, XL, QB>& st, const T* k0, const T* v0) __attribute__((always_inline)) {
         T8 rk[PREFETCH ? NKC : 1], rv[PREFETCH ? NVC : 1];
         // buffer descriptors of the segment's K / Vt (wave-uniform); per-lane byte offsets are 32-bit and the
         // tile advance goes into the scalar offset, so a full tile costs no address VALU at all
@@ -298,14 +302,17 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             // x^T = K Q'^T - m : the accumulator starts at -m, so the MFMA result is the exponent argument
             // (kept in registers across tiles where the budget allows: re-broadcasting it costs 16 v_mov per tile, a
             // sixth of the VALU instructions of a kernel that is VALU-issue bound — profiles/r01_attn_notes.txt)
-            f32x16 cneg;
-            if (PERSIST_C) {
-                cneg = st.cn;
-            } else {
+            f32x16 cneg[QB];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cneg[r] = -st.m;
+            for (int j = 0; j < QB; ++j) {
+                if (PERSIST_C) {
+                    cneg[j] = st.cn[j];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cneg[j][r] = -st.m[j];
+                }
             }
-            f32x16 sc[2];
+            f32x16 sc[QB][2];
             const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
             // k-step outer, key-block inner: consecutive MFMAs go to DIFFERENT accumulators, so the dependent
             // chain of one block never stalls the matrix pipe (the block-outer order measured ~45 % of the tile time)
@@ -322,8 +329,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < NQK; ++ks) {
-                    sc[0] = mfma32(kf[ks & 1][0], qf[ks], ks ? sc[0] : cneg);
-                    sc[1] = mfma32(kf[ks & 1][1], qf[ks], ks ? sc[1] : cneg);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        sc[j][0] = mfma32(kf[ks & 1][0], qf[j][ks], ks ? sc[j][0] : cneg[j]);
+                        sc[j][1] = mfma32(kf[ks & 1][1], qf[j][ks], ks ? sc[j][1] : cneg[j]);
+                    }
                     if (ks + 2 < NQK) {
                         kf[ks & 1][0] = *reinterpret_cast<const T8*>(kt + (ks + 2) * 16);
                         kf[ks & 1][1] = *reinterpret_cast<const T8*>(kt + 32 * KLD + (ks + 2) * 16);
@@ -331,73 +341,98 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
-            sc[0] = mfma32(*reinterpret_cast<const T8*>(kt), qf[0], cneg);
-            sc[1] = (FULL || nb > 1) ? mfma32(*reinterpret_cast<const T8*>(kt + 32 * KLD), qf[0], cneg) : cneg;
 #pragma unroll
-            for (int ks = 1; ks < NQK; ++ks) {
-                sc[0] = mfma32(*reinterpret_cast<const T8*>(kt + ks * 16), qf[ks], sc[0]);
-                if (FULL || nb > 1) sc[1] = mfma32(*reinterpret_cast<const T8*>(kt + 32 * KLD + ks * 16), qf[ks], sc[1]);
+                for (int ks = 0; ks < NQK; ++ks) {
+                    const T8 k0f = *reinterpret_cast<const T8*>(kt + ks * 16);
+                    const T8 k1f = *reinterpret_cast<const T8*>(kt + 32 * KLD + ks * 16);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        sc[j][0] = mfma32(k0f, qf[j][ks], ks ? sc[j][0] : cneg[j]);
+                        if (FULL || nb > 1) sc[j][1] = mfma32(k1f, qf[j][ks], ks ? sc[j][1] : cneg[j]);
+                        else if (ks == 0)   sc[j][1] = cneg[j];
+                    }
+                }
             }
-            }
-            // lane (q, hi): sc[b][r] belongs to key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
+            // lane (q, hi): sc[j][b][r] belongs to key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
             if (!FULL) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int j = 0; j < QB; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (key0 + 32 * b + 16 * (r >> 3) + 8 * hi + (r & 7) >= L) sc[b][r] = -1e30f;
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (key0 + 32 * b + 16 * (r >> 3) + 8 * hi + (r & 7) >= L) sc[j][b][r] = -1e30f;
             }
-            // head-room check: one v_max3 chain over this lane's 32 arguments, wave-uniform decision
-            float xm = fmaxf(sc[0][0], sc[0][1]);
+            // head-room check: one v_max3 chain over this lane's 32 arguments per query block, wave-uniform decision
+            float xm[QB];
 #pragma unroll
-            for (int i = 1; i < 16; ++i) xm = fmaxf(fmaxf(xm, sc[i >> 3][(2 * i) & 15]), sc[i >> 3][(2 * i + 1) & 15]);
-            if (st.fresh || __any(xm > XTH)) {
+            for (int j = 0; j < QB; ++j) {
+                xm[j] = fmaxf(sc[j][0][0], sc[j][0][1]);
+#pragma unroll
+                for (int i = 1; i < 16; ++i)
+                    xm[j] = fmaxf(fmaxf(xm[j], sc[j][i >> 3][(2 * i) & 15]), sc[j][i >> 3][(2 * i + 1) & 15]);
+            }
+            float xall = xm[0];
+#pragma unroll
+            for (int j = 1; j < QB; ++j) xall = fmaxf(xall, xm[j]);
+            if (st.fresh || __any(xall > XTH)) {
                 // slow path (first tile of a row, or a score out-grew the head-room): move the reference to the
                 // row maximum, rescale O (its ones-row = l included) and shift this tile's arguments in registers
-                const float rowmax = max_halves(xm);
-                const float shift = st.fresh ? rowmax : fmaxf(rowmax, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-shift);
-                st.m += shift;
+#pragma unroll
+                for (int j = 0; j < QB; ++j) {
+                    const float rowmax = max_halves(xm[j]);
+                    const float shift = st.fresh ? rowmax : fmaxf(rowmax, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-shift);
+                    st.m[j] += shift;
+                    if (PERSIST_C) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st.cn[j][r] = -st.m[j];
+                        asm volatile("" : "+v"(st.cn[j]));     // opaque: keeps the compiler from re-deriving it from m per tile
+                    }
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st.o[j][d][r] *= alpha;
+                    if (XL) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st.ol[j][r] *= alpha;
+                    }
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[j][b][r] -= shift;
+                }
                 st.fresh = false;
-                if (PERSIST_C) {
+            }
+            T8 pf[QB][4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) st.cn[r] = -st.m;
-                    asm volatile("" : "+v"(st.cn));        // opaque: keeps the compiler from re-deriving it from m per tile
-                }
-#pragma unroll
-                for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st.o[d][r] *= alpha;
-                if (XL) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st.ol[0][r] *= alpha;
-                }
+            for (int j = 0; j < QB; ++j)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[b][r] -= shift;
-            }
-            T8 pf[4];
+                    for (int u = 0; u < 2; ++u) {
+                        f32x8 pv;
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    f32x8 pv;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
+                        for (int e = 0; e < 8; ++e) {
+                            pv[e] = __builtin_amdgcn_exp2f(sc[j][b][8 * u + e]);
+                        }
+                        pf[j][2 * b + u] = cvt8<T>(pv);
                     }
-                    pf[2 * b + u] = cvt8<T>(pv);
-                }
-            // O^T += Vt P^T   (the ones row / ones block accumulates the row sums)
+            // O^T += Vt P^T   (the ones row / ones block accumulates the row sums); a V^T fragment read serves all QB blocks
             const T* vt = Vs + buf * DV * VLD + l31 * VLD + hi * 8;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 if (FULL || kk < 2 * nb) {
 #pragma unroll
-                    for (int d = 0; d < NDB; ++d)
-                        st.o[d] = mfma32(*reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16), pf[kk], st.o[d]);
-                    if (XL) st.ol[0] = mfma32(onesf, pf[kk], st.ol[0]);
+                    for (int d = 0; d < NDB; ++d) {
+                        const T8 vf = *reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16);
+#pragma unroll
+                        for (int j = 0; j < QB; ++j) st.o[j][d] = mfma32(vf, pf[j][kk], st.o[j][d]);
+                    }
+                    if (XL) {
+#pragma unroll
+                        for (int j = 0; j < QB; ++j) st.ol[j] = mfma32(onesf, pf[j][kk], st.ol[j]);
+                    }
                 }
             }
         };
@@ -439,20 +474,36 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         }
     };
 
-    auto init = [&](OState<NDB, XL>& st) {
-        st.m = 0.f;
+    typedef OState<NDB, XL, QB> State;
+    auto init = [&](State& st) {
         st.fresh = true;
-        st.cn = zero16();
-        if (PERSIST_C) asm volatile("" : "+v"(st.cn));
 #pragma unroll
-        for (int d = 0; d < NDB; ++d) st.o[d] = zero16();
-        st.ol[0] = zero16();
+        for (int j = 0; j < QB; ++j) {
+            st.m[j] = 0.f;
+            st.cn[j] = zero16();
+            if (PERSIST_C) asm volatile("" : "+v"(st.cn[j]));
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) st.o[j][d] = zero16();
+            st.ol[j] = zero16();
+        }
     };
     // 1 / (row sum) of a finished state: the sum sits in the ones-row of O^T at the lanes of half 0
-    auto inv_l = [&](const OState<NDB, XL>& st) __attribute__((always_inline)) {
-        const float lv = XL ? st.ol[0][0] : st.o[LBLK][LREG];
+    auto inv_l = [&](const State& st, int j) __attribute__((always_inline)) {
+        const float lv = XL ? st.ol[j][0] : st.o[j][LBLK][LREG];
         const float partner = other_half(lv);          // executed by every lane (cross-half permute)
         return 1.f / (hi ? partner : lv);
+    };
+    // res (+)= w * O / l  for every query block of the wave
+    auto finish = [&](f32x16 (&res)[QB][NDB], const State& st, float w, bool add) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            const float sc_ = w * inv_l(st, j);
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) {
+                if (add) res[j][d] += st.o[j][d] * sc_;
+                else     res[j][d] = st.o[j][d] * sc_;
+            }
+        }
     };
 
     const T* k_own = Kg + (int64_t)kvf * a.k_fs;
@@ -462,15 +513,13 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const T* k_end = Kg + (int64_t)a.end * a.k_fs;
     const T* v_end = Vg + (int64_t)a.end * a.vt_fs;
 
-    OState<NDB, XL> st;
+    State st;
     init(st);
-    f32x16 res[NDB];
+    f32x16 res[QB][NDB];
 
     if (MODE == AID_MODE_PLAIN) {
         run(st, k_own, v_own);
-        const float inv = inv_l(st);
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
+        finish(res, st, 1.f, false);
     } else if (cf < 0.f || (a.fused && ((cf == 0.f && kvf == a.begin) || (cf == 1.f && kvf == a.end)))) {
         // (1) negative coefficient = this frame is PLAIN inside an INNER / OUTER launch (the unconditional half of
         //     a classifier-free-guidance batch rides in the same call);
@@ -478,9 +527,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         //     every key leaves softmax(QK^T)V unchanged (SURVEY.md §4 invariant), so one pass over the own keys is
         //     the same result with half the work.
         run(st, k_own, v_own);
-        const float inv = inv_l(st);
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
+        finish(res, st, 1.f, false);
     } else if (MODE == AID_MODE_INNER) {
         if (a.fused) run(st, k_own, v_own);
         // coefficient exactly 0 / 1: the lerp is the end-point frame itself; interior frames read the
@@ -489,79 +536,92 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         else if (cf == 1.f) run(st, k_end, v_end);
         else                run(st, reinterpret_cast<const T*>(a.k2) + h * D + (int64_t)fr * a.k_fs,
                                 reinterpret_cast<const T*>(a.vt2) + (int64_t)(h * D) * a.ldvt + (int64_t)fr * a.vt_fs);
-        const float inv = inv_l(st);
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) res[d] = st.o[d] * inv;
+        finish(res, st, 1.f, false);
     } else {
         if (a.fused) run(st, k_own, v_own);
 #pragma unroll
-        for (int d = 0; d < NDB; ++d) res[d] = zero16();
-        if (cf != 1.f) {                                    // begin side, weight (1 - c)
-            OState<NDB, XL> sb = st;
-            run(sb, k_beg, v_beg);
-            const float w = (1.f - cf) * inv_l(sb);
+        for (int j = 0; j < QB; ++j)
 #pragma unroll
-            for (int d = 0; d < NDB; ++d) res[d] = sb.o[d] * w;
+            for (int d = 0; d < NDB; ++d) res[j][d] = zero16();
+        if (cf != 1.f) {                                    // begin side, weight (1 - c)
+            State sb = st;
+            run(sb, k_beg, v_beg);
+            finish(res, sb, 1.f - cf, false);
         }
         if (cf != 0.f) {                                    // end side, weight c
             run(st, k_end, v_end);
-            const float w = cf * inv_l(st);
-#pragma unroll
-            for (int d = 0; d < NDB; ++d) res[d] += st.o[d] * w;
+            finish(res, st, cf, true);
         }
     }
 
     // ---- epilogue: lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3} ------------------------
-    const int q = q0 + l31;
-    if (q < a.s) {
-        const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
-        T* orow = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q * a.ldo + h * D;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+    for (int j = 0; j < QB; ++j) {
+        const int q = q0 + 32 * j + l31;
+        if (q < a.s) {
+            const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
+            T* orow = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q * a.ldo + h * D;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dv = 32 * d + 8 * g + 4 * hi;
-                if (dv < D) {
-                    f32x4 v;
+            for (int d = 0; d < NDB; ++d)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = res[d][4 * g + e] * osc;
-                    if (a.accumulate) {
-                        const f32x4 old = up4<T>(*reinterpret_cast<const T4*>(orow + dv));
-                        v += old;
+                for (int g = 0; g < 4; ++g) {
+                    const int dv = 32 * d + 8 * g + 4 * hi;
+                    if (dv < D) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = res[j][d][4 * g + e] * osc;
+                        if (a.accumulate) {
+                            const f32x4 old = up4<T>(*reinterpret_cast<const T4*>(orow + dv));
+                            v += old;
+                        }
+                        *reinterpret_cast<T4*>(orow + dv) = cvt4<T>(v);
                     }
-                    *reinterpret_cast<T4*>(orow + dv) = cvt4<T>(v);
                 }
-            }
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D, int MODE, int NW>
+template <typename T, int D, int MODE, int NW, int QB>
 static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
-    const size_t smem = (size_t)(attn_prefetch(D, NW) ? 2 : 1) * (KT * (DK + 8) + DV * VLD) * sizeof(T);
+    const size_t smem = (size_t)((attn_prefetch(D, NW) || QB > 1) ? 2 : 1) * (KT * (DK + 8) + DV * VLD) * sizeof(T);
     static PerDevice<bool> attr_set;
     bool* done = attr_set.slot();
     if (!done) return hipErrorInvalidDevice;
     if (!*done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW, QB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         *done = true;
     }
     const int grid = p.nqb * p.a.n_frames * p.a.heads;
-    hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW>), dim3(grid), dim3(NW * 64), smem, stream, p);
+    hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW, QB>), dim3(grid), dim3(NW * 64), smem, stream, p);
     return hipGetLastError();
 }
 
-// Four waves (128 query rows) per workgroup for every shape: one-wave workgroups were measured slower
+// Four waves per workgroup for every shape: one-wave workgroups were measured slower
 // even at S = 64 (profiles/r01_attn_small_shapes.txt) — the K/V staging cost per query row quadruples.
 static int attn_nw(const AidAttnArgs&) { return 4; }
 
+// query blocks (of 32 rows) per wave: 2 where a (frame, head) has enough rows to fill 256-row workgroups
+// (development knob AID_ATTN_QB = 1 / 2 forces it)
+static int attn_qb(const AidAttnArgs& a) {
+    const char* env = getenv("AID_ATTN_QB");          // read per call: tools/kbench.py flips it inside one process
+    const int force = env ? atoi(env) : 0;
+    if (a.d != 40 && a.d != 64) return 1;
+    if (force == 1 || force == 2) return force;
+    return 1;
+}
+
 template <typename T, int D, int MODE>
 static hipError_t launch_nw(AttnKParams& p, hipStream_t stream) {
+    if ((D == 40 || D == 64) && attn_qb(p.a) == 2) {
+        p.nqb = (p.a.s + 255) / 256;
+        return launch_variant<T, D, MODE, 4, (D == 40 || D == 64) ? 2 : 1>(p, stream);
+    }
     p.nqb = (p.a.s + 127) / 128;
-    return launch_variant<T, D, MODE, 4>(p, stream);
+    return launch_variant<T, D, MODE, 4, 1>(p, stream);
 }
 
 template <typename T, int D>
@@ -633,8 +693,12 @@ bool attn_head_dim_supported(int d) { return d == 40 || d == 64 || d == 80 || d 
 const char* attn_variant_name(const AidAttnArgs& a) {
     static thread_local char name[64];
     static const char* modes[] = {"plain", "inner", "outer"};
-    snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
-             modes[a.mode], attn_nw(a));
+    if (attn_qb(a) == 2)
+        snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d,qb2>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
+                 modes[a.mode], attn_nw(a));
+    else
+        snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
+                 modes[a.mode], attn_nw(a));
     return name;
 }
 

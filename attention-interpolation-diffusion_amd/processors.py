@@ -406,6 +406,9 @@ class HipIPAdapterAttnProcessor(nn.Module):
         self.to_k_ip, self.to_v_ip = ip_attn.to_k_ip, ip_attn.to_v_ip
         return self
 
+    def fused_sublayer(self, attn, norm, hidden_states, encoder_hidden_states=None, ctx_index=None):
+        return hidden_states + self(attn, norm(hidden_states), encoder_hidden_states)
+
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  scale: float = 1.0, ip_adapter_masks=None):
         if ip_adapter_masks is not None:
@@ -433,6 +436,10 @@ class _IPBase(InterpolatedAttnProcessor):
         self.num_tokens = ip_attn.num_tokens if hasattr(ip_attn, "num_tokens") else (16,)
         self.scale = ip_attn.scale if hasattr(ip_attn, "scale") else None
         self.ip_attn = ip_attn
+
+    def fused_sublayer(self, attn, norm, hidden_states, encoder_hidden_states=None, ctx_index=None):
+        """``h + attn(norm(h), ctx)`` as three steps (the one-call form covers the text processors only)."""
+        return hidden_states + self(attn, norm(hidden_states), encoder_hidden_states)
 
     def _fallback(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb):
         """De-activated: the wrapped processor, like the reference (interpolation.py:248-251).  A wrapped object that

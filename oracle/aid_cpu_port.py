@@ -31,8 +31,10 @@ def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> 
 
 @torch.no_grad()
 def processor_call(x: torch.Tensor, ctx: Optional[torch.Tensor], wq, wk, wv, wo, bo, heads: int, mode: str,
-                   fused: bool, coef: Optional[torch.Tensor]) -> torch.Tensor:
-    """One attention-processor call, fp32 on the CPU.  mode: plain | outer | inner."""
+                   fused: bool, coef: Optional[torch.Tensor], only_heads: Optional[int] = None) -> torch.Tensor:
+    """One attention-processor call, fp32 on the CPU.  mode: plain | outer | inner.
+    ``only_heads``: timing aid — run the attention core for the first k heads only (the other heads' output stays
+    uninitialised); the projections always run in full.  bench.py times k = 1 and k = 2 and extrapolates linearly."""
     e = x if ctx is None else ctx
     q, k, v = x @ wq.T, e @ wk.T, e @ wv.T
     n, s, c = q.shape
@@ -40,7 +42,7 @@ def processor_call(x: torch.Tensor, ctx: Optional[torch.Tensor], wq, wk, wv, wo,
     qh, kh, vh = _heads(q, heads), _heads(k, heads), _heads(v, heads)
     out = torch.empty(n, heads, s, c // heads, dtype=x.dtype)
     cf = None if coef is None else coef.to(x.dtype).view(-1, 1, 1)
-    for h in range(heads):
+    for h in range(heads if only_heads is None else min(only_heads, heads)):
         qi, ki, vi = qh[:, h], kh[:, h], vh[:, h]
         if mode == "plain":
             out[:, h] = _attend(qi, ki, vi, scale)

@@ -1,0 +1,207 @@
+"""GPU: depth parity and end-to-end pipeline parity (north_star "latents within 1e-3 rel-L2").
+
+(1) Depth: the residual stream ``h += attn(norm(h), ctx)`` chained through ALL 32 (SD1.5, fp16) / 140 (SDXL, bf16)
+    attention layers of one UNet pass at reduced S (full widths, so the shipped head dims and GEMM paths run), for an AID
+    pass and a plain pass, HIP vs the fp64 oracle chain — the error after every layer is recorded, its growth bounded.
+(2) Pipelines: ``interpolate_single`` (batch 3, activate_aid / deactivate_aid per step) and the N-frame ``interpolate``
+    (batched CFG, guide-prompt contexts) over the stand-in denoiser for several DDIM steps, HIP vs the same loop with
+    every attention layer evaluated by the fp64 oracle.
+Measured values are written to gpurun_out/depth_parity.json when AID_WRITE_MEASUREMENTS=1."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aid_oracle as O
+from util import rel_l2, to_np64
+
+pytestmark = pytest.mark.gpu
+
+import aid_amd  # noqa: E402
+from aid_amd.loop import install_sequence_processors, set_aid_active  # noqa: E402
+from aid_amd.pipelines import (DDIMSchedulerLite, InterpolationStableDiffusionPipeline,  # noqa: E402
+                               InterpolationStableDiffusionXLPipeline, StackDenoiser)
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(key, value):
+    if os.environ.get("AID_WRITE_MEASUREMENTS") != "1":
+        return
+    path = os.path.join(ROOT, "gpurun_out", "depth_parity.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[key] = value
+    json.dump(data, open(path, "w"), indent=1)
+
+
+def _w(m, heads):
+    return O.AttnWeights(*(to_np64(t) for t in (m.to_q.weight, m.to_k.weight, m.to_v.weight, m.to_out[0].weight,
+                                                 m.to_out[0].bias)), heads)
+
+
+def _oracle_layer(stack, i, h64, ctx64, mode, fused, coef):
+    """One sublayer  h + attn(LayerNorm(h), ctx)  in fp64 with the layer's (fp16 / bf16-valued) weights."""
+    m, nrm, (s, c, heads, is_cross) = stack.layers[i], stack.norms[i], stack.shapes[i]
+    hn = O.layer_norm(h64, to_np64(nrm.weight), to_np64(nrm.bias), nrm.eps)
+    ctx = ctx64 if is_cross else None
+    w = _w(m, heads)
+    if mode == "plain":
+        a = O.plain_attention(hn, ctx, w)
+    elif mode == "outer":
+        a = O.outer_attention(hn, ctx, w, coef, fused)
+    else:
+        a = O.inner_attention(hn, ctx, w, coef, fused)
+    return h64 + a
+
+
+# BOUNDS: rel-L2 of the residual stream after the LAST layer of each resolution level (HIP storage dtype vs fp64).
+# One sublayer measures ~3e-4 (fp16) / ~2.5e-3 (bf16) on the attention term; the stream itself is re-rounded to the
+# storage dtype after every layer (eps/2 = 2.4e-4 fp16, 2e-3 bf16 relative per rounding), errors add in quadrature over
+# the L layers of a level.  Bounds = ~2x the measured values (gpurun_out/depth_parity.json, profiles/r02_depth_parity.json).
+DEPTH_BOUND = {"sd15": 4e-3, "sdxl": 3e-2}
+
+
+@pytest.mark.parametrize("model,dtype,early", [("sd15", torch.float16, "fused_inner"), ("sdxl", torch.bfloat16, "fused_outer")])
+def test_depth_parity_chained_through_every_layer(model, dtype, early):
+    n = 7
+    stack = aid_amd.AttnStackUNet(model, dtype=dtype, device=DEV, scale_down=16)
+    install_sequence_processors(stack, n, early=early, num_inference_steps=50)
+    g = torch.Generator().manual_seed(77)
+    xs = {k: torch.randn(n, k[0], k[1], generator=g).to(dtype) for k in stack.level_shapes()}
+    ctx = torch.randn(n, stack.text_len, stack.cross_dim, generator=g).to(dtype)
+    coef = next(iter(stack.attn_processors.values())).coef.to(dtype).float().numpy()
+    mode, fused = ("outer" if early.endswith("outer") else "inner"), early.startswith("fused")
+    report = {}
+    for step_mode in (mode, "plain"):
+        set_aid_active(stack, step_mode != "plain")
+        hs = {k: v.to(DEV) for k, v in xs.items()}
+        hs64 = {k: to_np64(v) for k, v in xs.items()}
+        ctx_d, ctx64 = ctx.to(DEV), to_np64(ctx)
+        curve = []
+        for i, (m, nrm, (s, c, h, is_cross)) in enumerate(zip(stack.layers, stack.norms, stack.shapes)):
+            hs[(s, c)] = m.processor.fused_sublayer(m, nrm, hs[(s, c)], ctx_d if is_cross else None)
+            hs64[(s, c)] = _oracle_layer(stack, i, hs64[(s, c)], ctx64, step_mode, fused, coef)
+            curve.append(rel_l2(to_np64(hs[(s, c)]), hs64[(s, c)]))
+        final = {f"{k[0]}x{k[1]}": rel_l2(to_np64(hs[k]), hs64[k]) for k in hs}
+        report[step_mode] = dict(first_layer=curve[0], worst=max(curve), final=final, layers=len(curve),
+                                 every_8th=curve[7::8])
+        assert max(final.values()) < DEPTH_BOUND[model], (step_mode, final)
+        assert max(curve) < DEPTH_BOUND[model]
+        # growth over depth stays far below linear accumulation of the per-layer error
+        assert max(curve) < 0.5 * len(curve) * max(curve[0], 1e-4)
+    _record(f"depth_{model}", report)
+
+
+class OracleDenoiser(torch.nn.Module):
+    """StackDenoiser.forward in fp64 with every attention layer evaluated by the oracle; reads the activation state /
+    coefficients / riders of the processors installed on the HIP denoiser it mirrors."""
+
+    def __init__(self, hip: StackDenoiser):
+        super().__init__()
+        self.hip = hip
+        self.latent_hw, self.in_channels = hip.latent_hw, 4
+        self.dummy = torch.nn.Parameter(torch.zeros(1, dtype=torch.float64), requires_grad=False)
+
+    attn_processors = property(lambda self: self.hip.attn_processors)
+
+    def set_attn_processor(self, p):
+        self.hip.set_attn_processor(p)
+
+    def forward(self, sample, timestep=None, encoder_hidden_states=None, added_cond_kwargs=None, return_dict=False, **kw):
+        st = self.hip.stack
+        n = sample.shape[0]
+        flat = sample.reshape(n, -1).double().numpy()
+        tshift = 0.0 if timestep is None else float(timestep) * self.hip.time_scale
+        hs = {}
+        for (s, c) in st.level_shapes():
+            tok = (flat @ to_np64(self.hip.lift[f"{s}_{c}"])).reshape(n, s, 8)
+            hs[(s, c)] = np.tile(tok, (1, 1, c // 8)) + tshift
+        ctx_all = encoder_hidden_states.double().numpy()
+        for i, (m, (s, c, h, is_cross)) in enumerate(zip(st.layers, st.shapes)):
+            proc = m.processor
+            n_aid = n - proc.plain_tail if proc.activated else 0
+            idx = proc.ctx_index
+            ctx = ctx_all if idx is None or ctx_all.shape[0] == n else None
+            if ctx is None:
+                ctx = ctx_all[idx]
+            elif idx is not None:                      # repeated contexts were passed: rows by first occurrence
+                first = [idx.index(r) for r in range(max(idx) + 1)]
+                ctx = ctx_all[[first[j] for j in idx]]
+            mode = "plain" if not proc.activated else proc._mode
+            coef = proc.coef.to(self.hip.dtype).float().numpy()
+            hcur = hs[(s, c)]
+            if mode == "plain":
+                hs[(s, c)] = _oracle_layer(st, i, hcur, ctx, "plain", False, None)
+            else:
+                a = _oracle_layer(st, i, hcur[:n_aid], ctx[:n_aid], mode, proc.is_fused, coef)
+                if n_aid < n:
+                    a = np.concatenate([a, _oracle_layer(st, i, hcur[n_aid:], ctx[n_aid:], "plain", False, None)])
+                hs[(s, c)] = a
+        out = np.zeros_like(flat)
+        for (s, c) in st.level_shapes():
+            hm = hs[(s, c)].reshape(n, s, c // 8, 8).mean(axis=2)
+            out = out + hm.reshape(n, s * 8) @ to_np64(self.hip.drop[f"{s}_{c}"])
+        out = out / len(st.level_shapes())
+        return (torch.from_numpy(out).view_as(sample),)
+
+    def parameters(self, recurse=True):
+        return iter([self.dummy])
+
+
+PIPE_BOUND = {torch.float16: 5e-3, torch.bfloat16: 4e-2}     # rel-L2 of the final latents, ~2x measured
+
+
+def _embs(g, cc, xl=False):
+    base = (torch.randn(1, 77, cc, generator=g), torch.randn(1, 77, cc, generator=g))
+    return base + ((torch.randn(1, 32, generator=g), torch.randn(1, 32, generator=g)) if xl else ())
+
+
+@pytest.mark.parametrize("model,dtype,atype", [("sd15", torch.float16, "fused_inner"), ("sdxl", torch.bfloat16, "fused_outer")])
+def test_interpolate_single_end_to_end_vs_oracle_loop(model, dtype, atype):
+    steps = 6
+    hip = StackDenoiser(model, dtype=dtype, device=DEV, scale_down=16 if model == "sd15" else 32, latent_hw=(8, 8))
+    cls = InterpolationStableDiffusionXLPipeline if model == "sdxl" else InterpolationStableDiffusionPipeline
+    g = torch.Generator().manual_seed(9)
+    l0, l1 = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    es, ee = _embs(g, hip.stack.cross_dim, model == "sdxl"), _embs(g, hip.stack.cross_dim, model == "sdxl")
+    rd = lambda t: tuple(e.to(dtype).float() for e in t)     # noqa: E731   both runs see the dtype-rounded embeddings
+    es, ee = rd(es), rd(ee)
+    pipe = cls(hip, DDIMSchedulerLite())
+    pipe.load_aid(t=0.5, is_fused=True, atype=atype)
+    out = pipe.interpolate_single(0.35, latent_start=l0, latent_end=l1, embeds_start=es, embeds_end=ee,
+                                  num_inference_steps=steps, warmup_ratio=0.5, output_type="latent")["images"]
+    ora = cls(OracleDenoiser(hip), DDIMSchedulerLite())
+    ref = ora.interpolate_single(0.35, latent_start=l0.to(dtype).double(), latent_end=l1.to(dtype).double(),
+                                 embeds_start=tuple(e.double() for e in es), embeds_end=tuple(e.double() for e in ee),
+                                 num_inference_steps=steps, warmup_ratio=0.5, output_type="latent")["images"]
+    err = rel_l2(to_np64(out), ref.numpy())
+    _record(f"interpolate_single_{model}", dict(steps=steps, rel_l2=err))
+    assert out.shape == (3, 4, 8, 8) and err < PIPE_BOUND[dtype], err
+
+
+@pytest.mark.parametrize("guided", [False, True])
+def test_n_frame_interpolate_end_to_end_vs_oracle_loop(guided):
+    dtype, steps, size = torch.float16, 4, 5
+    hip = StackDenoiser("sd15", dtype=dtype, device=DEV, scale_down=16, latent_hw=(8, 8))
+    g = torch.Generator().manual_seed(10)
+    l0, l1 = torch.randn(1, 4, 8, 8, generator=g).to(dtype), torch.randn(1, 4, 8, 8, generator=g).to(dtype)
+    rd = lambda t: tuple(e.to(dtype).float() for e in t)     # noqa: E731
+    es, ee, eg = rd(_embs(g, 768)), rd(_embs(g, 768)), rd(_embs(g, 768))
+    kw = dict(size=size, num_inference_steps=steps, warmup_ratio=0.5, early="fused_outer", guidance_scale=4.0,
+              output_type="latent")
+    pipe = InterpolationStableDiffusionPipeline(hip, DDIMSchedulerLite())
+    out = pipe.interpolate(l0, l1, embeds_start=es, embeds_end=ee, embeds_guide=eg if guided else None, **kw)
+    two = pipe.interpolate(l0, l1, embeds_start=es, embeds_end=ee, embeds_guide=eg if guided else None,
+                           batched_cfg=False, **kw)
+    assert torch.equal(out, two)                               # one batched call per step == the reference's two calls
+    ora = InterpolationStableDiffusionPipeline(OracleDenoiser(hip), DDIMSchedulerLite())
+    dbl = lambda t: tuple(e.double() for e in t)               # noqa: E731
+    ref = ora.interpolate(l0.double(), l1.double(), embeds_start=dbl(es), embeds_end=dbl(ee),
+                          embeds_guide=dbl(eg) if guided else None, **kw)
+    err = rel_l2(to_np64(out), ref.numpy())
+    _record(f"interpolate_n{size}_{'guided' if guided else 'lerp'}", dict(steps=steps, rel_l2=err))
+    assert out.shape == (size, 4, 8, 8) and err < PIPE_BOUND[dtype], err

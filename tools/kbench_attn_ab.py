@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Same-process interleaved A/B of attention-kernel variants (development knobs read per call by the library) at the
+launch shapes of the two bench stacks: 7 AID frames + 7 plain riders, BetaPPF(50, 50) coefficients.
+usage: python tools/kbench_attn_ab.py "AID_ATTN_QB=1" "AID_ATTN_QB=2" [--rounds 5] [--iters 6] [--shapes sdxl,sd15]
+Prints per shape and variant: median us per launch over the rounds, algorithmic and executed TFLOP/s."""
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import aid_amd  # noqa: E402
+from aid_amd import ops  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+opt = lambda k, d: int(sys.argv[sys.argv.index(k) + 1]) if k in sys.argv else d     # noqa: E731
+ROUNDS, ITERS = opt("--rounds", 5), opt("--iters", 6)
+which = sys.argv[sys.argv.index("--shapes") + 1].split(",") if "--shapes" in sys.argv else ["sdxl", "sd15"]
+variants = [dict(kv.split("=") for kv in a.split(",") if kv) for a in args] or [{}]
+dev = torch.device("cuda:0")
+lib = aid_amd._lib.load()
+
+SHAPES = {
+    "sdxl": [("sdxl S4096 d64 H10", torch.bfloat16, 4096, 4096, 10, 64, ["outer", "plain"]),
+             ("sdxl S1024 d64 H20", torch.bfloat16, 1024, 1024, 20, 64, ["outer", "plain"]),
+             ("sdxl S1024 x77 d64", torch.bfloat16, 1024, 77, 20, 64, ["outer"])],
+    "sd15": [("sd15 S4096 d40 H8", torch.float16, 4096, 4096, 8, 40, ["inner", "plain"]),
+             ("sd15 S4096 x77 d40", torch.float16, 4096, 77, 8, 40, ["inner"])],
+}
+
+
+def one(fn):
+    lib.aid_profile_begin()
+    for _ in range(ITERS):
+        fn()
+    buf = (aid_amd._lib.AidProfileEntry * 4096)()
+    n = lib.aid_profile_end(buf, 4096)
+    e = [x for x in buf[:n] if x.kernel.decode().startswith("aid_attn")]
+    return sum(x.ms for x in e) / len(e) * 1e3, e[0].flops, e[0].flops_executed, e[0].kernel.decode()
+
+
+for grp in which:
+    for tag, dt, s, l, h, d, modes in SHAPES[grp]:
+        n, c = 7, h * d
+        q = torch.randn(2 * n, s, c, device=dev).to(dt)
+        k = torch.randn(2 * n, l, c, device=dev).to(dt)
+        vt = torch.randn(2 * n, c, (l + 7) // 8 * 8, device=dev).to(dt)
+        cf = aid_amd.generate_beta_tensor(n, 50, 50)
+        cf[0], cf[-1] = 0, 1
+        vals = cf.to(dt).float().tolist() + [-1.0] * n
+        coef = torch.tensor(vals, device=dev)
+        out = torch.empty_like(q)
+        for mode in modes:
+            fused = mode != "plain"
+            segx = ops.executed_segments(mode, fused, vals, 2 * n, None, 0, n - 1)
+            fn = lambda: ops.attn_fwd(q, k, vt, h, l=l, mode=mode, fused=fused, coef=coef if fused else None,      # noqa: E731
+                                      begin=0, end=n - 1, out=out, n_plain=n if fused else 0, seg_executed=segx)
+            res = {i: [] for i in range(len(variants))}
+            names = {}
+            for i, v in enumerate(variants):                  # warm every variant (lazy attributes)
+                os.environ.update(v); fn(); fn()
+            torch.cuda.synchronize()
+            for r in range(ROUNDS):
+                for i, v in enumerate(variants):
+                    os.environ.update(v)
+                    us, fl, flx, nm = one(fn)
+                    res[i].append(us); names[i] = (fl, flx, nm)
+            for i, v in enumerate(variants):
+                us = statistics.median(res[i])
+                fl, flx, nm = names[i]
+                print(f"{tag:20s} {mode:6s} {str(v):28s} {nm:34s} {us:9.1f} us  alg {fl / us / 1e6:7.1f}  exec {flx / us / 1e6:7.1f} TF/s"
+                      f"   (min {min(res[i]):.1f})", flush=True)
+print("done")
