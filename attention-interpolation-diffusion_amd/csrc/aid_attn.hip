@@ -604,14 +604,15 @@ static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
 // even at S = 64 (profiles/r01_attn_small_shapes.txt) — the K/V staging cost per query row quadruples.
 static int attn_nw(const AidAttnArgs&) { return 4; }
 
-// query blocks (of 32 rows) per wave: 2 where a (frame, head) has enough rows to fill 256-row workgroups
-// (development knob AID_ATTN_QB = 1 / 2 forces it)
+// query blocks (of 32 rows) per wave.  Measured (profiles/r02_attn_notes.txt, tools/kbench_attn_ab.py): 64 rows per wave
+// pays only where the kernel still fits two waves per SIMD — d = 40 PLAIN (254 VGPRs, +4 % at S = 4096); every other
+// variant needs > 256 VGPRs, runs one wave per SIMD and loses 25-35 %.  Development knob AID_ATTN_QB = 1 / 2 forces it.
 static int attn_qb(const AidAttnArgs& a) {
-    const char* env = getenv("AID_ATTN_QB");          // read per call: tools/kbench.py flips it inside one process
+    const char* env = getenv("AID_ATTN_QB");          // read per call: tools/kbench_attn_ab.py flips it inside one process
     const int force = env ? atoi(env) : 0;
     if (a.d != 40 && a.d != 64) return 1;
     if (force == 1 || force == 2) return force;
-    return 1;
+    return (a.d == 40 && a.mode == AID_MODE_PLAIN && a.s >= 2048 && a.l >= 1024) ? 2 : 1;
 }
 
 template <typename T, int D, int MODE>

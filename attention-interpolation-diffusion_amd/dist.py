@@ -124,6 +124,76 @@ def gather_owned(local: torch.Tensor, shard: FrameShard, group=None) -> torch.Te
     return torch.cat([o[: b - a] for o, (a, b) in zip(out, parts)], dim=0)
 
 
+# ---------------------------------------------------------------------------------------------
+# SURVEY.md §8e "alternative" / §8f.4: no replicated end points — every rank runs ONLY the frames it owns and the two
+# owner ranks broadcast the projected keys / values of frames 0 and N-1 once per self-attention layer.  (Cross-attention
+# needs no exchange: the end-point frames' TEXT contexts are part of the once-per-run conditioning broadcast, every rank
+# projects them itself — 77 rows.)  Removes the 2x recompute of the 16-frames-on-8-GPUs layout at the price of one small
+# collective per self-attention layer (SDXL: 70 per UNet pass, 2.6 - 5.2 MB per tensor).
+# ---------------------------------------------------------------------------------------------
+def owned_shard(n_frames: int, world_size: int, rank: int) -> FrameShard:
+    """Frame shard WITHOUT replicated end points: the local batch is exactly the owned frames."""
+    start, stop = partition_frames(n_frames, world_size)[rank]
+    return FrameShard(n_frames, world_size, rank, (start, stop), tuple(range(start, stop)), (0, stop - start))
+
+
+class EndpointExchange:
+    """Per-layer hand-off of the end-point frames' projected keys / values (reference semantics: every frame attends
+    with K/V of frames 0 and N-1, interpolation.py:626-635 / 760-775).  ``exchange(k, vt, n)`` takes the rank's projected
+    ``k [n + 2, L, C]`` / ``vt [n + 2, C, Lp]`` (rows ``n`` and ``n + 1`` are free, see ``ops.project_kv(extra_rows=2)``),
+    fills row ``n`` with frame 0's and row ``n + 1`` with frame N-1's keys / values — broadcast from the ranks that own
+    them (RCCL "nccl" backend on device tensors; gloo hops through the host in the 1-GPU development mode) — and returns
+    the rows to pass as ``begin`` / ``end`` to the attention call."""
+
+    def __init__(self, n_frames: int, world_size: int, rank: int, group=None):
+        parts = partition_frames(n_frames, world_size)
+        self.n_frames, self.world_size, self.rank, self.group = n_frames, world_size, rank, group
+        self.owner_begin = next(r for r, (a, b) in enumerate(parts) if a <= 0 < b)
+        self.owner_end = next(r for r, (a, b) in enumerate(parts) if a <= n_frames - 1 < b)
+        a, b = parts[rank]
+        self.local_begin = 0 if rank == self.owner_begin else None              # local row of frame 0 on its owner
+        self.local_end = (b - a - 1) if rank == self.owner_end else None         # local row of frame N-1 on its owner
+        self.calls = 0
+
+    def _bcast(self, t: torch.Tensor, src: int) -> None:
+        if not (dist.is_available() and dist.is_initialized()):
+            if self.world_size != 1:
+                raise RuntimeError("EndpointExchange over several ranks needs an initialised process group")
+            return
+        if _needs_host_hop(t, self.group):
+            h = t.cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src, group=self.group)
+
+    def exchange(self, k: torch.Tensor, vt: torch.Tensor, n: int) -> Tuple[int, int]:
+        if k.shape[0] != n + 2 or vt.shape[0] != n + 2:
+            raise ValueError("k / vt need two free rows behind the local frames (ops.project_kv(extra_rows=2))")
+        for row, local, src in ((n, self.local_begin, self.owner_begin), (n + 1, self.local_end, self.owner_end)):
+            if local is not None:
+                k[row].copy_(k[local])
+                vt[row].copy_(vt[local])
+            self._bcast(k[row], src)
+            self._bcast(vt[row], src)
+        self.calls += 1
+        return n, n + 1
+
+
+def decode_sharded(decode, latents_local: torch.Tensor, shard: FrameShard, group=None) -> torch.Tensor:
+    """every rank decodes the latents of the frames it OWNS (``decode``: the VAE decoder, third-party)
+    and the decoded images — not the latents — are all-gathered: the VAE work is sharded like the denoising, and the
+    full image sequence ``[N, 3, H, W]`` ends up on every rank."""
+    lo, hi = shard.owned_local
+    images = decode(latents_local[lo:hi]) if hi > lo else None
+    if images is None:                      # a rank that owns nothing still takes part in the collective
+        probe = decode(latents_local[:1])
+        images = probe[:0]
+    pseudo = FrameShard(shard.n_frames, shard.world_size, shard.rank, shard.owned, tuple(range(*shard.owned)),
+                        (0, shard.n_owned))
+    return gather_owned(images, pseudo, group=group)
+
+
 def expected_speedup(n_frames: int, world_size: int) -> float:
     """Ideal speed-up of the sharded run over one GPU: N / max local batch (replicated end points cap it;
     e.g. 16 frames on 8 GPUs -> 16 / 4 = 4x)."""

@@ -161,13 +161,15 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optio
     return out
 
 
-def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """k = e @ wk.T  [F, L, C]  and  V^T = wv @ e^T  [F, C, Lp]  (Lp = L rounded up to 8) in one launch."""
+def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, extra_rows: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """k = e @ wk.T  [F, L, C]  and  V^T = wv @ e^T  [F, C, Lp]  (Lp = L rounded up to 8) in one launch.
+    ``extra_rows``: allocate that many more (uninitialised) frame rows behind the F projected ones — room for the
+    end-point frames' keys / values a rank receives from their owners (dist.EndpointExchange)."""
     f, l, cc = e.shape
     c = wk.shape[0]
     lp = (l + 7) // 8 * 8
-    k = torch.empty(f, l, c, dtype=e.dtype, device=e.device)
-    vt = torch.empty(f, c, lp, dtype=e.dtype, device=e.device)
+    k = torch.empty(f + extra_rows, l, c, dtype=e.dtype, device=e.device)
+    vt = torch.empty(f + extra_rows, c, lp, dtype=e.dtype, device=e.device)
     gemm_nt([
         dict(a=e, b=wk, c=k, m=f * l, n=c, k=cc, lda=cc, ldb=cc, ldc=c),
         dict(a=wv, b=e, c=vt, m=c, n=l, k=cc, lda=cc, ldb=cc, ldc=lp, batch=f,
@@ -207,9 +209,9 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
     a.coef, a.frame_scale, a.kv_map = _ptr(coef), _ptr(frame_scale), _ptr(kv_map)
     if mode == "inner":
         # interpolated K / V^T of the interior frames (one streaming launch), read by the attention kernel
-        if kv_map is not None or f != n:
+        if kv_map is not None or f < n:
             raise ValueError("inner mode needs one key/value row per frame (no kv_map)")
-        k2, vt2 = torch.empty_like(k), torch.empty_like(vt)
+        k2, vt2 = torch.empty_like(k[:n]), torch.empty_like(vt[:n])
         with _on(q.device):
             _lib.check(lib.aid_lerp_kv(k.data_ptr(), vt.data_ptr(), k2.data_ptr(), vt2.data_ptr(), coef.data_ptr(), n,
                                        begin % f, end % f, k.shape[1] * k.shape[2], vt.shape[1] * vt.shape[2], dt,

@@ -13,7 +13,7 @@ import torch  # noqa: E402
 import aid_amd  # noqa: E402
 from aid_amd import ops  # noqa: E402
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
 opt = lambda k, d: int(sys.argv[sys.argv.index(k) + 1]) if k in sys.argv else d     # noqa: E731
 ROUNDS, ITERS = opt("--rounds", 5), opt("--iters", 6)
 which = sys.argv[sys.argv.index("--shapes") + 1].split(",") if "--shapes" in sys.argv else ["sdxl", "sd15"]

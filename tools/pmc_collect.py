@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Collect rocprofv3 PMC counters per launch of every aid_* kernel of the bench workloads -> profiles/r02_pmc.json.
+
+Procedure (MI355X_MICROARCH.md, HBM / PMC-slot sections): every counter group is its OWN rocprofv3 pass with
+--kernel-trace only (never combined with sys / hip / memory-copy tracing), over
+    bench.py --workload W --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-also
+  pass 1  FETCH_SIZE                      pass 2  WRITE_SIZE        (they do not fit one TCC pass)
+  pass 3  SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY
+          SQ_ACTIVE_INST_ANY
+  pass 4  SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES
+          SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU
+  pass 5  GRBM_GUI_ACTIVE                 (kernel duration in shader-clock cycles -> effective clock, MFMA-busy fraction)
+Per kernel (named as bench.py's roofline object names them) the averages per launch are stored, plus
+  hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (gfx950: FETCH_SIZE reports half the bytes of a 16 B/lane
+                                                                 streaming read; WRITE_SIZE is uncalibrated)
+  mfma_busy_frac       = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs * 256 CUs * GRBM_GUI_ACTIVE)
+  valu_per_mfma        = SQ_INSTS_VALU / SQ_INSTS_MFMA   (SQ_INSTS_VALU counts the MFMAs too)
+  clock_ghz            = GRBM_GUI_ACTIVE / rocprofv3 kernel duration
+usage (on the GPU box, from the repo root):  python tools/pmc_collect.py [out.json] [--workloads sdxl,sd15]"""
+import collections, csv, glob, json, os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODES = {"0": "plain", "1": "inner", "2": "outer"}
+PASSES = [
+    ["FETCH_SIZE"], ["WRITE_SIZE"],
+    ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES",
+     "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"],
+    ["SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU",
+     "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_SALU"],
+    ["GRBM_GUI_ACTIVE"],
+]
+
+
+def bench_name(sym):
+    """kernel symbol -> the name bench.py's roofline object uses"""
+    dt = "bf16" if "IDF16b" in sym else "f16"
+    m = re.search(r"aid_attn_kernelIDF16b?_?Li(\d+)ELi(\d)ELi(\d)ELi(\d)", sym)
+    if m:
+        qb = ",qb2" if m.group(4) == "2" else ""
+        return f"aid_attn<{dt},d{m.group(1)},{MODES[m.group(2)]},nw{m.group(3)}{qb}>"
+    m = re.search(r"aid_attn_short_kernelIDF16b?_?Li(\d+)ELi(\d)", sym)
+    if m:
+        return f"aid_attn_short<{dt},d{m.group(1)},{MODES[m.group(2)]}>"
+    for k in ("aid_gemm_nt_pp_kernel", "aid_gemm_nt_pipe_kernel", "aid_gemm_nt_kernel", "aid_lerp_kv_kernel",
+              "aid_layernorm_kernel"):
+        if k in sym:
+            return f"{k.replace('aid_lerp_kv_kernel', 'aid_lerp_kv').replace('aid_layernorm_kernel', 'aid_layernorm')}<{dt}>"
+    return None
+
+
+def collect(workload, counters):
+    out = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+    cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "2", "--no-graph",
+           "--no-cpu-baseline", "--no-roofline", "--no-also", "--min-seconds", "0"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    f = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)[0]
+    per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    dur = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        nm = bench_name(r["Kernel_Name"])
+        if nm is None:
+            continue
+        per[nm][r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            dur[nm][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    res = {}
+    for nm, disp in per.items():
+        n = len(disp)
+        avg = collections.defaultdict(float)
+        for d in disp.values():
+            for c, v in d.items():
+                avg[c] += v / n
+        res[nm] = dict(avg, launches=n)
+        if dur[nm]:
+            res[nm]["_ns"] = sum(dur[nm].values()) / len(dur[nm])
+    return res
+
+
+def main():
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    wls = sys.argv[sys.argv.index("--workloads") + 1].split(",") if "--workloads" in sys.argv else ["sdxl", "sd15"]
+    out = argv[0] if argv else os.path.join(ROOT, "profiles", "r02_pmc.json")
+    res = {"_comment": __doc__.split("usage")[0].strip(), "models": {}}
+    for wl in wls:
+        merged = collections.defaultdict(dict)
+        for counters in PASSES:
+            try:
+                got = collect(wl, counters)
+            except Exception as e:                                   # a counter this rocprofv3 does not know: keep going
+                print(f"[pmc] pass {counters} failed for {wl}: {e}", file=sys.stderr)
+                continue
+            for nm, vals in got.items():
+                ns = vals.pop("_ns", None)
+                merged[nm].update(vals)
+                if ns is not None and counters == ["GRBM_GUI_ACTIVE"]:
+                    merged[nm]["profiled_ns_per_launch"] = ns
+        table = {}
+        for nm, v in sorted(merged.items()):
+            e = {k: round(x, 1) for k, x in v.items() if k != "launches"}
+            e["launches"] = v.get("launches")
+            if "FETCH_SIZE" in v:
+                e["hbm_bytes_per_launch"] = int((2 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024)
+            if v.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+                e["mfma_busy_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * v["GRBM_GUI_ACTIVE"]), 4)
+            if v.get("SQ_INSTS_MFMA"):
+                e["valu_per_mfma"] = round(v.get("SQ_INSTS_VALU", 0.0) / v["SQ_INSTS_MFMA"], 2)
+            if v.get("GRBM_GUI_ACTIVE") and v.get("profiled_ns_per_launch"):
+                e["clock_ghz"] = round(v["GRBM_GUI_ACTIVE"] / v["profiled_ns_per_launch"], 3)
+            if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and "SQ_VALU_MFMA_COEXEC_CYCLES" in v:
+                e["coexec_frac_of_mfma_busy"] = round(v["SQ_VALU_MFMA_COEXEC_CYCLES"] / v["SQ_VALU_MFMA_BUSY_CYCLES"], 4)
+            table[nm] = e
+        stack = {"sdxl": "sdxl", "sd15": "sd15"}.get(wl, wl)
+        res["models"][stack] = table
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res["models"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
