@@ -59,6 +59,12 @@ class InterpolatedAttnProcessor(nn.Module):
         # (PAID guide prompt: [start, guide x (N-2), end] = 3 distinct contexts, sequence.py).  The keys / values of
         # a shared context are then projected once instead of once per frame.  None = one context per frame.
         self.ctx_index: Optional[Sequence[int]] = None
+        # build-specific (SURVEY.md §8e alternative / §8f.4): frame-sharded run WITHOUT replicated end points.  The batch
+        # holds only the rank's own frames; ``endpoint_exchange`` (dist.EndpointExchange) fetches the projected keys /
+        # values of frames 0 and N-1 from their owner ranks in every self-attention call, and ``endpoint_ctx``
+        # ([2, L, Cc]: text contexts of frames 0 and N-1, known to every rank) serves the cross-attention calls.
+        self.endpoint_exchange = None
+        self.endpoint_ctx: Optional[torch.Tensor] = None
 
     # ``coef`` stays a plain CPU tensor attribute like the reference's (interpolation.py:21-27, 42); assigning it
     # (``activate(t)``, ``proc.coef = ...``) refreshes the device copies at once, so a replayed graph never sees the
@@ -247,6 +253,27 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
     begin, end = 0, (n_aid - 1) if mode != "plain" else -1
     ctx_map = idx = None
     ctx_index = proc.ctx_index if ctx_index is None else ctx_index
+    exchange = getattr(proc, "endpoint_exchange", None)
+    if exchange is not None and mode != "plain":
+        if ln is not None or add_to is not None or ctx_index is not None:
+            raise NotImplementedError("the end-point exchange layout runs the plain processor call (no sublayer fusion, "
+                                      "no shared-context map)")
+        n = x.shape[0]
+        if ctx is None:                               # self-attention: keys / values of frames 0 / N-1 come from their owners
+            q = ops.linear(x, wq)
+            k, vt = ops.project_kv(x, wk, wv, extra_rows=2)
+            begin, end = exchange.exchange(k, vt, n)
+            o = ops.attn_fwd(q, k, vt, attn.heads, l=x.shape[1], mode=mode, fused=proc.is_fused, coef=coef,
+                             begin=begin, end=end, n_plain=proc.plain_tail)
+            return _epilogue(attn, ops.linear(o, wo, bo), residual, shape4)
+        if proc.endpoint_ctx is None:
+            raise RuntimeError("endpoint_exchange is set: cross-attention needs `endpoint_ctx` (text contexts of the two "
+                               "end-point frames)")
+        ctx = torch.cat([ctx, proc.endpoint_ctx.to(ctx.dtype)], dim=0).contiguous()
+        _, ctx_map, _ = _shared_context(proc._ctx_cache, list(range(n)) + [n, n + 1], ctx, n + 2)
+        y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode, fused=proc.is_fused, coef=coef,
+                              begin=n, end=n + 1, ctx_map=ctx_map[:n], n_plain=proc.plain_tail)
+        return _epilogue(attn, y, residual, shape4)
     if ctx is not None and ctx_index is not None:
         ctx, ctx_map, idx = _shared_context(proc._ctx_cache, ctx_index, ctx, x.shape[0])
         if mode != "plain":

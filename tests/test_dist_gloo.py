@@ -99,3 +99,42 @@ def test_gather_owned_single_process():
     sh = adist.frame_shard(5, 1, 0)
     t = torch.arange(5.0).reshape(5, 1)
     assert torch.equal(adist.gather_owned(t, sh), t)
+
+
+# ---- end-point K/V exchange instead of replicated end points, sharded VAE decode ----------------------
+def _worker_f4(rank, world, port, n_frames, q):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(5)
+        kf = torch.randn(n_frames, 6, 8, generator=g)               # "projected keys" of every frame (same on all ranks)
+        vf = torch.randn(n_frames, 8, 8, generator=g)
+        sh = adist.owned_shard(n_frames, world, rank)
+        n = sh.n_local
+        ex = adist.EndpointExchange(n_frames, world, rank)
+        k = torch.cat([kf[list(sh.index)], torch.full((2, 6, 8), float("nan"))])
+        vt = torch.cat([vf[list(sh.index)], torch.full((2, 8, 8), float("nan"))])
+        b, e = ex.exchange(k, vt, n)
+        ok = (b, e) == (n, n + 1) and torch.equal(k[b], kf[0]) and torch.equal(k[e], kf[-1]) \
+            and torch.equal(vt[b], vf[0]) and torch.equal(vt[e], vf[-1]) and torch.equal(k[:n], kf[list(sh.index)])
+        lat = torch.arange(n_frames, dtype=torch.float32).view(-1, 1, 1, 1).expand(n_frames, 4, 2, 2)[list(sh.index)]
+        imgs = adist.decode_sharded(lambda z: z.repeat(1, 1, 2, 2)[:, :3] * 2.0, lat, sh)
+        want = torch.arange(n_frames, dtype=torch.float32).view(-1, 1, 1, 1).expand(n_frames, 3, 4, 4) * 2.0
+        ok = ok and imgs.shape == (n_frames, 3, 4, 4) and torch.equal(imgs, want)
+        q.put((rank, bool(ok), ex.owner_begin, ex.owner_end))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [5, 16])
+def test_endpoint_exchange_and_sharded_decode_world_size_2(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_f4, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [True, True], res
+    assert res[0][2:] == (0, 1)

@@ -43,3 +43,51 @@ def test_rccl_world_size_1_collectives_on_device_tensors():
             adist.gather_owned(lat, adist.frame_shard(5, 2, 0))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["outer", "inner"])
+@pytest.mark.parametrize("cross", [False, True], ids=["self", "cross"])
+def test_endpoint_exchange_layout_equals_replicated_layout(kind, cross):
+    """SURVEY.md §8f.4 on one rank: the batch without replicated end points + EndpointExchange (self-attention K/V rows
+    handed over per layer, cross-attention from `endpoint_ctx`) gives the frames the same outputs as the standard
+    layout, against the fp64 oracle.  Interior-only batch: frames 1..N-2 of an N-frame sequence, as an interior rank
+    of a sharded run would hold them — the end-point rows come from a second 'owner' exchange object."""
+    import numpy as np
+    from oracle import aid_oracle as O
+    from util import TOL, rel_l2, to_np64
+    dtype, n, s, heads, d, l, cc = torch.float16, 5, 96, 2, 40, 77, 64
+    c = heads * d
+    g = torch.Generator().manual_seed(21)
+    attn = aid_amd.AttnShim(c, heads, cc if cross else None, dtype=dtype, device="cuda:0")
+    x = torch.randn(n, s, c, generator=g).to(dtype).cuda()
+    ctx = torch.randn(n, l, cc, generator=g).to(dtype).cuda() if cross else None
+    cls = aid_amd.OuterInterpolatedAttnProcessor if kind == "outer" else aid_amd.InnerInterpolatedAttnProcessor
+    full = cls(size=n, is_fused=True, alpha=4, beta=4)
+    w = O.AttnWeights(*(to_np64(t) for t in (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
+                                              attn.to_out[0].weight, attn.to_out[0].bias)), heads)
+    coef = full.coef.to(dtype).float().numpy()
+    fn = O.outer_attention if kind == "outer" else O.inner_attention
+    ref = fn(to_np64(x), None if ctx is None else to_np64(ctx), w, coef, True)
+
+    # one rank owning everything: rows 0 / N-1 are copied into the two extra rows
+    own = cls(size=n, is_fused=True, alpha=4, beta=4)
+    own.endpoint_exchange = adist.EndpointExchange(n, 1, 0)
+    if cross:
+        own.endpoint_ctx = torch.stack([ctx[0], ctx[-1]])
+    y = own(attn, x, encoder_hidden_states=ctx)
+    assert rel_l2(to_np64(y), ref) < TOL[dtype]
+    assert own.endpoint_exchange.calls == (0 if cross else 1)
+
+    # an interior "rank": only frames 1..N-2 in the batch; its exchange object is fed by a stand-in for the owners
+    class FromOwners(adist.EndpointExchange):
+        def exchange(self, k, vt, m):
+            kk, vv = aid_amd.ops.project_kv(x[[0, n - 1]].contiguous(), attn.to_k.weight, attn.to_v.weight)
+            k[m], k[m + 1], vt[m], vt[m + 1] = kk[0], kk[1], vv[0], vv[1]
+            return m, m + 1
+    inner = cls(size=n - 2, is_fused=True)
+    inner.coef = full.coef[1:-1].clone()
+    inner.endpoint_exchange = FromOwners(n, 1, 0)
+    if cross:
+        inner.endpoint_ctx = torch.stack([ctx[0], ctx[-1]])
+    yi = inner(attn, x[1:-1].contiguous(), encoder_hidden_states=None if ctx is None else ctx[1:-1].contiguous())
+    assert rel_l2(to_np64(yi), ref[1:-1]) < TOL[dtype]
