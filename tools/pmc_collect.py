@@ -13,9 +13,12 @@ Procedure (MI355X_MICROARCH.md, HBM / PMC-slot sections): every counter group is
 Per kernel (named as bench.py's roofline object names them) the averages per launch are stored, plus
   hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (gfx950: FETCH_SIZE reports half the bytes of a 16 B/lane
                                                                  streaming read; WRITE_SIZE is uncalibrated)
-  mfma_busy_frac       = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs * 256 CUs * GRBM_GUI_ACTIVE)
-  valu_per_mfma        = SQ_INSTS_VALU / SQ_INSTS_MFMA   (SQ_INSTS_VALU counts the MFMAs too)
-  clock_ghz            = GRBM_GUI_ACTIVE / rocprofv3 kernel duration
+  cycles               = GRBM_GUI_ACTIVE / 8            (the counter is summed over the 8 XCDs' GRBMs)
+  mfma_busy_frac       = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs * 256 CUs * cycles)   (the counter = 32 x MFMAs issued: matrix-pipe
+                         occupancy incl. padded / row-sum MFMAs, at the clock the kernel really ran at)
+  valu_per_mfma        = (SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA   (SQ_INSTS_VALU counts the MFMAs too)
+  coexec_frac_of_mfma_busy = SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES  (matrix-pipe time with a VALU op in flight)
+  clock_ghz            = cycles / rocprofv3 kernel duration
 usage (on the GPU box, from the repo root):  python tools/pmc_collect.py [out.json] [--workloads sdxl,sd15]"""
 import collections, csv, glob, json, os, re, subprocess, sys, tempfile
 
@@ -78,7 +81,30 @@ def collect(workload, counters):
     return res
 
 
+def derive(e, v):
+    cyc = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    if cyc and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+        e["cycles_per_launch"] = round(cyc, 1)
+        e["mfma_busy_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 4)
+    if v.get("SQ_INSTS_MFMA"):
+        e["valu_per_mfma"] = round((v.get("SQ_INSTS_VALU", 0.0) - v["SQ_INSTS_MFMA"]) / v["SQ_INSTS_MFMA"], 2)
+    if cyc and v.get("profiled_ns_per_launch"):
+        e["clock_ghz"] = round(cyc / v["profiled_ns_per_launch"], 3)
+    if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and "SQ_VALU_MFMA_COEXEC_CYCLES" in v:
+        e["coexec_frac_of_mfma_busy"] = round(v["SQ_VALU_MFMA_COEXEC_CYCLES"] / v["SQ_VALU_MFMA_BUSY_CYCLES"], 4)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--rederive":        # recompute the derived fields of an existing file
+        res = json.load(open(sys.argv[2]))
+        res["_comment"] = __doc__.split("usage")[0].strip()
+        for t in res["models"].values():
+            for e in t.values():
+                for k in ("mfma_busy_frac", "valu_per_mfma", "clock_ghz", "coexec_frac_of_mfma_busy", "cycles_per_launch"):
+                    e.pop(k, None)
+                derive(e, e)
+        json.dump(res, open(sys.argv[3] if len(sys.argv) > 3 else sys.argv[2], "w"), indent=1)
+        return
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     wls = sys.argv[sys.argv.index("--workloads") + 1].split(",") if "--workloads" in sys.argv else ["sdxl", "sd15"]
     out = argv[0] if argv else os.path.join(ROOT, "profiles", "r02_pmc.json")
@@ -102,14 +128,7 @@ def main():
             e["launches"] = v.get("launches")
             if "FETCH_SIZE" in v:
                 e["hbm_bytes_per_launch"] = int((2 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024)
-            if v.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
-                e["mfma_busy_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * v["GRBM_GUI_ACTIVE"]), 4)
-            if v.get("SQ_INSTS_MFMA"):
-                e["valu_per_mfma"] = round(v.get("SQ_INSTS_VALU", 0.0) / v["SQ_INSTS_MFMA"], 2)
-            if v.get("GRBM_GUI_ACTIVE") and v.get("profiled_ns_per_launch"):
-                e["clock_ghz"] = round(v["GRBM_GUI_ACTIVE"] / v["profiled_ns_per_launch"], 3)
-            if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and "SQ_VALU_MFMA_COEXEC_CYCLES" in v:
-                e["coexec_frac_of_mfma_busy"] = round(v["SQ_VALU_MFMA_COEXEC_CYCLES"] / v["SQ_VALU_MFMA_BUSY_CYCLES"], 4)
+            derive(e, v)
             table[nm] = e
         stack = {"sdxl": "sdxl", "sd15": "sd15"}.get(wl, wl)
         res["models"][stack] = table
