@@ -72,6 +72,7 @@ template <int NDB, bool XL, int QB>
 struct OState {
     float  m[QB];
     bool   fresh;                       // no tile processed yet: the first tile sets the reference
+    bool   mz;                          // LAZY0: the reference of every row of this wave is still exactly 0
     f32x16 o[QB][NDB];
     f32x16 ol[QB];                      // only used when XL
     f32x16 cn[QB];                      // -m in all 16 registers (C operand of the first MFMA), kept when PERSIST_C
@@ -92,7 +93,11 @@ __device__ __forceinline__ f32x16 zero16() {
 // QB = 32-row query blocks per wave.  QB = 2 (64 query rows per wave): every K / V^T fragment read from LDS and every
 // staging pass / barrier serves twice the MFMAs, and the two blocks' independent MFMA chains give the scheduler
 // something to put between dependent instructions — at the price of one wave per SIMD (> 256 VGPRs).
-template <typename T, int D, int MODE, int NW, int QB>
+// PIPE = software-pipelined main loop (run_pipe below): the MFMAs of P V(t-1) and of Q K(t+1) are issued with the softmax
+// VALU work of tile t in the gaps between them, order pinned by sched_barrier — one wave then overlaps its own matrix
+// and vector work instead of running QK | softmax | PV back to back (tools/ubench/overlap.hip: 0.404 -> 0.341 us per
+// wave-tile in the register-only model at 3 waves / SIMD, 0.560 -> 0.419 at one).
+template <typename T, int D, int MODE, int NW, int QB, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) {
     typedef typename Vec<T>::v8 T8;
     typedef typename Vec<T>::v4 T4;
@@ -118,6 +123,12 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     static_assert(XL || ((D % 32) % 8 == 0 && (D % 32) < 32), "spare row must sit at a register boundary");
     // head-room (log2) of P = 2^x in the storage type before the row reference has to be raised
     constexpr float XTH = sizeof(T) == 2 && std::is_same<T, f16>::value ? 15.0f : 60.0f;
+    // LAZY0 (experiment, off): bf16 has the exponent range of fp32, so the row reference could start at 0 and stay there
+    // while every exponent argument is within +- 2^60 — the first product would then start from the constant 0 instead of
+    // a copy of the -m block (32 v_mov per tile, a third of the kernel's VALU instructions: profiles/r02_pmc.json).
+    // Measured: d64 plain 628 -> 639 us (no gain: the copies are not what the tile waits for), and the second code version
+    // of the first product pushes INNER / OUTER past 256 VGPRs (one wave per SIMD: outer 1207 -> 1665 us).  Not adopted.
+    constexpr bool LAZY0 = false;
     static_assert(D % 8 == 0, "head dim must be a multiple of 8");
     static_assert((KLD / 8) % 2 == 1 && (VLD / 8) % 2 == 1, "LDS row stride must be an odd number of 16-B slots");
 
@@ -314,6 +325,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             }
             f32x16 sc[QB][2];
             const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
+            auto qk = [&](auto zero_tag) __attribute__((always_inline)) {
+            constexpr bool ZERO = decltype(zero_tag)::value;
             // k-step outer, key-block inner: consecutive MFMAs go to DIFFERENT accumulators, so the dependent
             // chain of one block never stalls the matrix pipe (the block-outer order measured ~45 % of the tile time)
             if (FULL && KPIPE) {
@@ -331,8 +344,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 for (int ks = 0; ks < NQK; ++ks) {
 #pragma unroll
                     for (int j = 0; j < QB; ++j) {
-                        sc[j][0] = mfma32(kf[ks & 1][0], qf[j][ks], ks ? sc[j][0] : cneg[j]);
-                        sc[j][1] = mfma32(kf[ks & 1][1], qf[j][ks], ks ? sc[j][1] : cneg[j]);
+                        sc[j][0] = mfma32(kf[ks & 1][0], qf[j][ks], ks ? sc[j][0] : (ZERO ? zero16() : cneg[j]));
+                        sc[j][1] = mfma32(kf[ks & 1][1], qf[j][ks], ks ? sc[j][1] : (ZERO ? zero16() : cneg[j]));
                     }
                     if (ks + 2 < NQK) {
                         kf[ks & 1][0] = *reinterpret_cast<const T8*>(kt + (ks + 2) * 16);
@@ -347,12 +360,15 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     const T8 k1f = *reinterpret_cast<const T8*>(kt + 32 * KLD + ks * 16);
 #pragma unroll
                     for (int j = 0; j < QB; ++j) {
-                        sc[j][0] = mfma32(k0f, qf[j][ks], ks ? sc[j][0] : cneg[j]);
-                        if (FULL || nb > 1) sc[j][1] = mfma32(k1f, qf[j][ks], ks ? sc[j][1] : cneg[j]);
-                        else if (ks == 0)   sc[j][1] = cneg[j];
+                        sc[j][0] = mfma32(k0f, qf[j][ks], ks ? sc[j][0] : (ZERO ? zero16() : cneg[j]));
+                        if (FULL || nb > 1) sc[j][1] = mfma32(k1f, qf[j][ks], ks ? sc[j][1] : (ZERO ? zero16() : cneg[j]));
+                        else if (ks == 0)   sc[j][1] = ZERO ? zero16() : cneg[j];
                     }
                 }
             }
+            };
+            if (LAZY0 && st.mz) qk(std::true_type{});
+            else                qk(std::false_type{});
             // lane (q, hi): sc[j][b][r] belongs to key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
             if (!FULL) {
 #pragma unroll
@@ -375,9 +391,20 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             float xall = xm[0];
 #pragma unroll
             for (int j = 1; j < QB; ++j) xall = fmaxf(xall, xm[j]);
-            if (st.fresh || __any(xall > XTH)) {
+            bool need = __any(xall > XTH);
+            if (st.fresh) {
+                if (!LAZY0) {
+                    need = true;
+                } else {                                  // reference 0 is fine unless a whole row sits below the head-room
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) need = need || __any(max_halves(xm[j]) < -XTH);
+                    if (!need) st.fresh = false;
+                }
+            }
+            if (need) {
                 // slow path (first tile of a row, or a score out-grew the head-room): move the reference to the
                 // row maximum, rescale O (its ones-row = l included) and shift this tile's arguments in registers
+                st.mz = false;
 #pragma unroll
                 for (int j = 0; j < QB; ++j) {
                     const float rowmax = max_halves(xm[j]);
@@ -437,16 +464,276 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             }
         };
 
+
+        // ---- software-pipelined main loop over `nfp` FULL tiles (nfp odd, >= 3) ---------------------------------
+        // Tile t:  S(t) = K(t) Q'^T - m  (QK),  P(t) = 2^S(t)  (softmax VALU),  O^T += V^T(t) P(t)^T  (PV).
+        // Iteration i issues   phase A: the MFMAs of PV(i-1) with max3(S(i)) and the exponentials of key block 0 of
+        //                               S(i) (in place) between them;
+        //                      [rare] head-room decision for tile i: PV(i-1) is complete, so rescaling O here is safe;
+        //                      phase B: the MFMAs of QK(i+1) with the cvt of block 0, exp + cvt of block 1 -> P(i) and the
+        //                               LDS writes of the staged tiles between them.
+        // S(t) lives in sA / sB by the parity of t, P(t) in pA / pB; K(t) / V^T(t) in LDS buffer t & 1.  K runs one tile
+        // further ahead than V^T: iteration i stages K(i+2) and V^T(i) (loads issued at its start, written in phase B),
+        // one barrier per iteration.
+        auto run_pipe = [&](int nfp) __attribute__((always_inline)) {
+            static_assert(!PIPE || (QB == 1 && PREFETCH), "pipelined loop: one query block per wave, register staging");
+            constexpr int NPV = 4 * (NDB + (XL ? 1 : 0));       // MFMAs of one PV
+            constexpr int NQM = 2 * NQK;                        // MFMAs of one QK
+            constexpr int NOP = 32;                             // VALU micro-ops per phase
+            auto ld_k = [&](int t_) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < NKC; ++i)
+                    rk[PREFETCH ? i : 0] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sk0, kvo[i], t_ * KT * a.ldk * 2, 0));
+            };
+            auto ld_v = [&](int t_) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < NVC; ++i)
+                    rv[PREFETCH ? i : 0] = __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(sv0, vvo[i], t_ * KT * 2, 0));
+            };
+            auto wr_k = [&](int buf, int i) __attribute__((always_inline)) {      // chunk i of the staged K tile -> LDS
+                const int id = tid + i * NT;
+                if (NKC * NT != KCH && id >= KCH) return;
+                *reinterpret_cast<T8*>(Ks + buf * KT * KLD + (id / DC) * KLD + (id % DC) * 8) = rk[PREFETCH ? i : 0];
+            };
+            auto wr_v = [&](int buf, int i) __attribute__((always_inline)) {
+                const int id = tid + i * NT;
+                if (NVC * NT != VCH && id >= VCH) return;
+                *reinterpret_cast<T8*>(Vs + buf * DV * VLD + (id / (KT / 8)) * VLD + (id % (KT / 8)) * 8) = rv[PREFETCH ? i : 0];
+            };
+            auto cneg_of = [&]() __attribute__((always_inline)) {
+                f32x16 c;
+                if (PERSIST_C) {
+                    c = st.cn[0];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = -st.m[0];
+                }
+                return c;
+            };
+            // QK of the tile in LDS buffer `buf`, program order (prologue and the rare slow path)
+            auto qk_plain = [&](int buf, f32x16 (&s_)[2]) __attribute__((always_inline)) {
+                const f32x16 cneg = cneg_of();
+                const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
+#pragma unroll
+                for (int ks = 0; ks < NQK; ++ks) {
+                    s_[0] = mfma32(*reinterpret_cast<const T8*>(kt + ks * 16), qf[0][ks], ks ? s_[0] : cneg);
+                    s_[1] = mfma32(*reinterpret_cast<const T8*>(kt + 32 * KLD + ks * 16), qf[0][ks], ks ? s_[1] : cneg);
+                }
+            };
+            // VALU micro-ops.  Phase A, op k: 0..15 = the max3 chain over S, 16..31 = exp of S[0][k-16] in place.
+            auto op_a = [&](int k, f32x16 (&s_)[2], float& mx) __attribute__((always_inline)) {
+                // the empty asm pins the op where it is written: without it LLVM sinks the (pure) chain to its first use
+                // behind the MFMAs and the interleave is gone
+                if (k < 16) {
+                    if (k == 0) mx = fmaxf(s_[0][0], s_[0][1]);
+                    else        mx = fmaxf(fmaxf(mx, s_[k >> 3][(2 * k) & 15]), s_[k >> 3][(2 * k + 1) & 15]);
+                    asm volatile("" : "+v"(mx));
+                } else {
+                    float e = __builtin_amdgcn_exp2f(s_[0][k - 16]);
+                    asm volatile("" : "+v"(e));
+                    s_[0][k - 16] = e;
+                }
+            };
+            // Phase B, op k: 0..7 = cvt_pk of block 0 (exponentiated in phase A) -> P[0..1]; 8..23 = exp of S[1][k-8];
+            // 24..31 = cvt_pk of block 1 -> P[2..3]
+            auto op_b = [&](int k, f32x16 (&s_)[2], T8 (&p_)[4]) __attribute__((always_inline)) {
+                typedef typename Vec<T>::v2 T2;
+                if (k < 8 || k >= 24) {
+                    const int b = k < 8 ? 0 : 1, j = k < 8 ? k : k - 24;          // pair j of block b: elements 2j, 2j+1
+                    f32x2 v2;
+                    v2[0] = s_[b][2 * j];
+                    v2[1] = s_[b][2 * j + 1];
+                    T2 c2 = __builtin_convertvector(v2, T2);
+                    asm volatile("" : "+v"(c2));
+                    p_[2 * b + (j >> 2)][2 * (j & 3)] = c2[0];
+                    p_[2 * b + (j >> 2)][2 * (j & 3) + 1] = c2[1];
+                } else {
+                    float e = __builtin_amdgcn_exp2f(s_[1][k - 8]);
+                    asm volatile("" : "+v"(e));
+                    s_[1][k - 8] = e;
+                }
+            };
+            // head-room slow path for tile i (first tile of the wave, or a score out-grew the storage type's head-room): S(i)
+            // was partly exponentiated in place, so it is recomputed from K(i) (still in LDS buffer i & 1), the reference is
+            // moved to the row maximum, O is rescaled (PV(i-1) is complete) and block 0 is exponentiated again
+            // S of tile t straight from global memory in fragment layout (slow path only: the LDS buffer that held K(t) may
+            // already be receiving K(t+2) from a faster wave)
+            auto qk_global = [&](int t_, f32x16 (&s_)[2]) __attribute__((always_inline)) {
+                const f32x16 cneg = cneg_of();
+                const T* kg = k0 + (int64_t)(t_ * KT + krow) * a.ldk + hi * 8;
+#pragma unroll
+                for (int ks = 0; ks < NQK; ++ks) {
+                    const bool in = ks * 16 + hi * 8 < D;
+                    const T8 f0 = in ? *reinterpret_cast<const T8*>(kg + ks * 16) : zero8<T>();
+                    const T8 f1 = in ? *reinterpret_cast<const T8*>(kg + (int64_t)32 * a.ldk + ks * 16) : zero8<T>();
+                    s_[0] = mfma32(f0, qf[0][ks], ks ? s_[0] : cneg);
+                    s_[1] = mfma32(f1, qf[0][ks], ks ? s_[1] : cneg);
+                }
+            };
+            auto slow = [&](int i, f32x16 (&s_)[2]) __attribute__((always_inline)) {
+                qk_global(i, s_);
+                float xm = fmaxf(s_[0][0], s_[0][1]);
+#pragma unroll
+                for (int k = 1; k < 16; ++k) xm = fmaxf(fmaxf(xm, s_[k >> 3][(2 * k) & 15]), s_[k >> 3][(2 * k + 1) & 15]);
+                const float rowmax = max_halves(xm);
+                const float shift = st.fresh ? rowmax : fmaxf(rowmax, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-shift);
+                st.m[0] += shift;
+                st.fresh = false;
+                if (PERSIST_C) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st.cn[0][r] = -st.m[0];
+                    asm volatile("" : "+v"(st.cn[0]));
+                }
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st.o[0][d][r] *= alpha;
+                if (XL) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st.ol[0][r] *= alpha;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s_[0][r] = __builtin_amdgcn_exp2f(s_[0][r] - shift);
+                    s_[1][r] -= shift;
+                }
+            };
+            // one iteration; HAS_PV: PV(i-1) exists, HAS_KLD: K(i+2) exists, HAS_QK: tile i+1 exists
+            auto iter = [&](auto has_pv_t, auto has_kld_t, auto has_qk_t, int i, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2],
+                            T8 (&p_prev)[4], T8 (&p_cur)[4]) __attribute__((always_inline)) {
+                constexpr bool HAS_PV = decltype(has_pv_t)::value, HAS_KLD = decltype(has_kld_t)::value,
+                               HAS_QK = decltype(has_qk_t)::value;
+                const int bc = i & 1;
+                if (HAS_KLD) ld_k(i + 2);
+                ld_v(i);
+                // ---------------- phase A ----------------
+                float mx = 0.f;
+                if (HAS_PV) {
+                    const T* vt = Vs + (bc ^ 1) * DV * VLD + l31 * VLD + hi * 8;
+                    T8 vf[2][NDB];
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) vf[0][d] = *reinterpret_cast<const T8*>(vt + d * 32 * VLD);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        if (kk + 1 < 4) {
+#pragma unroll
+                            for (int d = 0; d < NDB; ++d)
+                                vf[(kk + 1) & 1][d] = *reinterpret_cast<const T8*>(vt + d * 32 * VLD + (kk + 1) * 16);
+                        }
+#pragma unroll
+                        for (int d = 0; d < NDB + (XL ? 1 : 0); ++d) {
+                            if (d < NDB) st.o[0][d] = mfma32(vf[kk & 1][d], p_prev[kk], st.o[0][d]);
+                            else         st.ol[0] = mfma32(onesf, p_prev[kk], st.ol[0]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int g = kk * (NDB + (XL ? 1 : 0)) + d;
+#pragma unroll
+                            for (int k = g * NOP / NPV; k < (g + 1) * NOP / NPV; ++k) op_a(k, s_cur, mx);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NOP; ++k) op_a(k, s_cur, mx);
+                }
+                if (st.fresh || __any(mx > XTH)) slow(i, s_cur);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---------------- phase B ----------------
+                if (HAS_QK) {
+                    const f32x16 cneg = cneg_of();
+                    const T* kt = Ks + (bc ^ 1) * KT * KLD + krow * KLD + hi * 8;
+                    T8 kf[2][2];
+                    kf[0][0] = *reinterpret_cast<const T8*>(kt);
+                    kf[0][1] = *reinterpret_cast<const T8*>(kt + 32 * KLD);
+                    if (NQK > 1) {
+                        kf[1][0] = *reinterpret_cast<const T8*>(kt + 16);
+                        kf[1][1] = *reinterpret_cast<const T8*>(kt + 32 * KLD + 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < NQK; ++ks) {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            s_nxt[b] = mfma32(kf[ks & 1][b], qf[0][ks], ks ? s_nxt[b] : cneg);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int g = 2 * ks + b;
+#pragma unroll
+                            for (int k = g * NOP / NQM; k < (g + 1) * NOP / NQM; ++k) op_b(k, s_cur, p_cur);
+                            // the staged tiles go to LDS in the last gaps (their loads were issued a phase and a half ago)
+                            if (g >= NQM - NKC - NVC) {
+                                const int w = g - (NQM - NKC - NVC);
+                                if (w < NKC) { if (HAS_KLD) wr_k(bc, w); }
+                                else         wr_v(bc, w - NKC);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (ks + 2 < NQK) {
+                            kf[ks & 1][0] = *reinterpret_cast<const T8*>(kt + (ks + 2) * 16);
+                            kf[ks & 1][1] = *reinterpret_cast<const T8*>(kt + 32 * KLD + (ks + 2) * 16);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NOP; ++k) op_b(k, s_cur, p_cur);
+#pragma unroll
+                    for (int w = 0; w < NVC; ++w) wr_v(bc, w);
+                }
+                __syncthreads();
+            };
+            static_assert(NKC + NVC <= 2 * NQK, "staging writes must fit the gaps of phase B");
+
+            f32x16 sA[2], sB[2];
+            T8 pA[4], pB[4];
+            // prologue: K(0), K(1) to LDS, S(0)
+            ld_k(0);
+#pragma unroll
+            for (int w = 0; w < NKC; ++w) wr_k(0, w);
+            ld_k(1);
+#pragma unroll
+            for (int w = 0; w < NKC; ++w) wr_k(1, w);
+            __syncthreads();
+            qk_plain(0, sA);
+            const std::true_type Y{};
+            const std::false_type N{};
+            iter(N, Y, Y, 0, sA, sB, pB, pA);                   // i = 0: S(0) -> P(0) in pA, S(1) in sB
+            int i = 1;
+            for (; i + 1 <= nfp - 3; i += 2) {                  // steady state, two iterations per trip (register sets swap)
+                iter(Y, Y, Y, i, sB, sA, pA, pB);
+                iter(Y, Y, Y, i + 1, sA, sB, pB, pA);
+            }
+            iter(Y, N, Y, nfp - 2, sB, sA, pA, pB);             // odd: no K tile left to stage
+            iter(Y, N, N, nfp - 1, sA, sB, pB, pA);             // even: last tile, no QK
+            {                                                   // PV(nfp - 1): P in pA, V^T in buffer 0
+                const T* vt = Vs + l31 * VLD + hi * 8;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d)
+                        st.o[0][d] = mfma32(*reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16), pA[kk], st.o[0][d]);
+                    if (XL) st.ol[0] = mfma32(onesf, pA[kk], st.ol[0]);
+                }
+            }
+            __syncthreads();
+        };
+
         const int nt = (L + KT - 1) / KT;
         const int nfull = L / KT;
+        int t = 0;
+        if (PIPE && nfull >= 3) {                       // pipelined over an odd number of full tiles, the rest below
+            const int nfp = (nfull & 1) ? nfull : nfull - 1;
+            run_pipe(nfp);
+            t = nfp;
+            if (t == nt) return;
+        }
         if (PREFETCH) {
-            if (nfull > 0) stage_load(0, std::true_type{});
-            else           stage_load(0, std::false_type{});
-            if (nfull > 0) stage_write(0, 0, std::true_type{});
-            else           stage_write(0, 0, std::false_type{});
+            if (t < nfull) stage_load(t * KT, std::true_type{});
+            else           stage_load(t * KT, std::false_type{});
+            if (t < nfull) stage_write(t & 1, t * KT, std::true_type{});
+            else           stage_write(t & 1, t * KT, std::false_type{});
             __syncthreads();
         }
-        int t = 0;
         for (; t < nfull; ++t) {                        // tiles with all 64 keys valid: no masks, no edge logic
             const int buf = PREFETCH ? (t & 1) : 0, key0 = t * KT;
             if (PREFETCH) {
@@ -477,6 +764,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     typedef OState<NDB, XL, QB> State;
     auto init = [&](State& st) {
         st.fresh = true;
+        st.mz = true;
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
             st.m[j] = 0.f;
@@ -582,7 +870,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D, int MODE, int NW, int QB>
+template <typename T, int D, int MODE, int NW, int QB, bool PIPE>
 static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
     const size_t smem = (size_t)((attn_prefetch(D, NW) || QB > 1) ? 2 : 1) * (KT * (DK + 8) + DV * VLD) * sizeof(T);
@@ -590,13 +878,13 @@ static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     bool* done = attr_set.slot();
     if (!done) return hipErrorInvalidDevice;
     if (!*done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW, QB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW, QB, PIPE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         *done = true;
     }
     const int grid = p.nqb * p.a.n_frames * p.a.heads;
-    hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW, QB>), dim3(grid), dim3(NW * 64), smem, stream, p);
+    hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW, QB, PIPE>), dim3(grid), dim3(NW * 64), smem, stream, p);
     return hipGetLastError();
 }
 
@@ -610,19 +898,33 @@ static int attn_nw(const AidAttnArgs&) { return 4; }
 static int attn_qb(const AidAttnArgs& a) {
     const char* env = getenv("AID_ATTN_QB");          // read per call: tools/kbench_attn_ab.py flips it inside one process
     const int force = env ? atoi(env) : 0;
-    if (a.d != 40 && a.d != 64) return 1;
+    if (a.d != 40 || a.mode != AID_MODE_PLAIN) return 1;         // the other 64-row variants are not built (see above)
     if (force == 1 || force == 2) return force;
     return (a.d == 40 && a.mode == AID_MODE_PLAIN && a.s >= 2048 && a.l >= 1024) ? 2 : 1;
 }
 
+// software-pipelined main loop.  Built for d = 40 (every mode) and d = 64 PLAIN; measured (profiles/r02_attn_notes.txt):
+// +5 % for d = 40 INNER (two waves per SIMD either way), neutral for d = 64 PLAIN (206 VGPRs: two waves per SIMD instead of
+// three), slower wherever the extra live tile pushes the kernel to one wave per SIMD (OUTER).  Default: d = 40 INNER on
+// segments of at least three full tiles; development knob AID_ATTN_PIPE = 0 / 1 forces it for the built variants.
+static bool attn_pipe(const AidAttnArgs& a) {
+    const char* env = getenv("AID_ATTN_PIPE");
+    const bool built = a.d == 40 || (a.d == 64 && a.mode == AID_MODE_PLAIN);
+    if (!built || a.l < 192) return false;
+    if (env) return atoi(env) != 0;
+    return a.d == 40 && a.mode == AID_MODE_INNER;
+}
+
 template <typename T, int D, int MODE>
 static hipError_t launch_nw(AttnKParams& p, hipStream_t stream) {
-    if ((D == 40 || D == 64) && attn_qb(p.a) == 2) {
+    if (D == 40 && MODE == AID_MODE_PLAIN && attn_qb(p.a) == 2) {
         p.nqb = (p.a.s + 255) / 256;
-        return launch_variant<T, D, MODE, 4, (D == 40 || D == 64) ? 2 : 1>(p, stream);
+        return launch_variant<T, D, MODE, 4, (D == 40 && MODE == AID_MODE_PLAIN) ? 2 : 1, false>(p, stream);
     }
     p.nqb = (p.a.s + 127) / 128;
-    return launch_variant<T, D, MODE, 4, 1>(p, stream);
+    constexpr bool CAN_PIPE = D == 40 || (D == 64 && MODE == AID_MODE_PLAIN);
+    if (CAN_PIPE && attn_pipe(p.a)) return launch_variant<T, D, MODE, 4, 1, CAN_PIPE>(p, stream);
+    return launch_variant<T, D, MODE, 4, 1, false>(p, stream);
 }
 
 template <typename T, int D>
@@ -696,6 +998,9 @@ const char* attn_variant_name(const AidAttnArgs& a) {
     static const char* modes[] = {"plain", "inner", "outer"};
     if (attn_qb(a) == 2)
         snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d,qb2>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
+                 modes[a.mode], attn_nw(a));
+    else if (attn_pipe(a))
+        snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d,pipe>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
                  modes[a.mode], attn_nw(a));
     else
         snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,

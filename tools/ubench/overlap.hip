@@ -82,64 +82,70 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
             pv_all(pf); SB();
         }
     } else {
-        // steady state: sc = scores of tile t (QK done in the previous iteration), pf = P of tile t-1
-        qk_all(sc);
-        for (int it = 0; it < iters; ++it) {
-            SB();
-            // ---- phase A: PV(t-1) (12 MFMAs) with max3(t) and exp quarters 0, 1 of tile t between them
-            float m = fmaxf(sc[0][0], sc[0][1]);
+        // steady state: sa = scores of tile t (QK done in the previous half-iteration), pa = P of tile t-1.
+        // Two half-iterations per loop trip with the register sets swapped (no copies).
+        f32x16 sa[2], sb[2];
+        bf16x8 pa[4], pb[4];
+        for (int i = 0; i < 4; ++i) pa[i] = pf[i];
+        qk_all(sa);
+        // phase A: PV(P_prev) (12 MFMAs) with max3(S_cur) + exp/cvt of the first 16 scores between them -> P_next[0..1]
+        // phase B: QK -> S_next (8 MFMAs) with exp/cvt of the other 16 scores between them -> P_next[2..3]
+        auto half = [&](f32x16 (&s_cur)[2], f32x16 (&s_next)[2], bf16x8 (&p_prev)[4], bf16x8 (&p_next)[4]) __attribute__((always_inline)) {
+            float m = fmaxf(s_cur[0][0], s_cur[0][1]);
+            f32x8 ea, eb;
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
-                o[i % 3] = mfma(vf[((i / 3) + (i % 3)) & 3], pf[i / 3], o[i % 3]);
+                o[i % 3] = mfma(vf[((i / 3) + (i % 3)) & 3], p_prev[i / 3], o[i % 3]);
                 SB();
-                if (i < 5) {                                         // 15 max3 in groups of 3
+                if (i < 5) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const int u = 1 + 3 * i + j;
-                        m = fmaxf(fmaxf(m, sc[u >> 3][(2 * u) & 15]), sc[u >> 3][(2 * u + 1) & 15]);
+                        m = fmaxf(fmaxf(m, s_cur[u >> 3][(2 * u) & 15]), s_cur[u >> 3][(2 * u + 1) & 15]);
                     }
-                } else if (i < 11) {                                 // 16 exp + 8 cvt in 6 groups: 3 exp (+ cvt pairs at the end)
-                    const int g = i - 5;                             // 0..5
+                } else if (i < 9) {                                  // 4 gaps x 4 exp
+                    const int g = i - 5;
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int e = 3 * g + j;                     // 0..17 -> 16 exps
-                        if (e < 16) scn[0][e] = __builtin_amdgcn_exp2f(sc[0][e]);     // staged in scn[0] as fp32 for now
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g + j;
+                        if (e < 8) ea[e] = __builtin_amdgcn_exp2f(s_cur[0][e]); else eb[e - 8] = __builtin_amdgcn_exp2f(s_cur[0][e]);
                     }
+                } else if (i == 9) {
+                    p_next[0] = cvt(ea);
+                } else if (i == 10) {
+                    p_next[1] = cvt(eb);
                 }
                 SB();
             }
             macc += m;
-            if (__any(m > 1e30f)) cneg[0] += 1.f;                    // the (rare) slow path decision sits between the phases
+            if (__any(m > 1e30f)) cneg[0] += 1.f;
             SB();
-            {   f32x8 a, b;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { a[e] = scn[0][e]; b[e] = scn[0][8 + e]; }
-                pfn[0] = cvt(a); pfn[1] = cvt(b);
-            }
-            SB();
-            // ---- phase B: QK(t+1) (8 MFMAs) with exp quarters 2, 3 of tile t between them
-            f32x16 s2[2];
-            f32x8 a, b;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int ks = i >> 1;
-                if (i & 1) s2[1] = mfma(kf[(ks + 1) & 3], q[ks], ks ? s2[1] : cneg);
-                else       s2[0] = mfma(kf[ks], q[ks], ks ? s2[0] : cneg);
+                if (i & 1) s_next[1] = mfma(kf[(ks + 1) & 3], q[ks], ks ? s_next[1] : cneg);
+                else       s_next[0] = mfma(kf[ks], q[ks], ks ? s_next[0] : cneg);
                 SB();
                 if (i < 4) {
-                    a[2 * i] = __builtin_amdgcn_exp2f(sc[1][2 * i]);  a[2 * i + 1] = __builtin_amdgcn_exp2f(sc[1][2 * i + 1]);
-                } else {
-                    b[2 * (i - 4)] = __builtin_amdgcn_exp2f(sc[1][8 + 2 * (i - 4)]);
-                    b[2 * (i - 4) + 1] = __builtin_amdgcn_exp2f(sc[1][9 + 2 * (i - 4)]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * i + j;
+                        if (e < 8) ea[e] = __builtin_amdgcn_exp2f(s_cur[1][e]); else eb[e - 8] = __builtin_amdgcn_exp2f(s_cur[1][e]);
+                    }
+                } else if (i == 4) {
+                    p_next[2] = cvt(ea);
+                } else if (i == 5) {
+                    p_next[3] = cvt(eb);
                 }
                 SB();
             }
-            pfn[2] = cvt(a); pfn[3] = cvt(b);
-            SB();
-            sc[0] = s2[0]; sc[1] = s2[1];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pf[i] = pfn[i];
+        };
+        for (int it = 0; it < iters; it += 2) {
+            half(sa, sb, pa, pb);
+            half(sb, sa, pb, pa);
         }
+        sc[0] = sa[0]; sc[1] = sa[1];
+        for (int i = 0; i < 4; ++i) pf[i] = pa[i];
     }
     float r = macc;
     for (int j = 0; j < 3; ++j) for (int i = 0; i < 16; ++i) r += o[j][i];
