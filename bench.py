@@ -184,15 +184,23 @@ def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
     """The CPU port ("port", oracle/aid_cpu_port.py: the oracle's arithmetic on torch CPU ops) on the host cores with
     torch.set_num_threads(all cores).  Bounded sample (~10-30 s): ONE transformer block (self + cross call) per
     resolution level, in the AID mode and in plain mode, on the 3-frame sub-batch [first, middle, last] of the same
-    synthetic inputs; the attention core of a call is timed for 1 and for 2 heads and extrapolated linearly to all
-    heads (projections run in full).  Scaled x n_frames / 3, x blocks per level, x pass counts, to the 50-step unit."""
+    synthetic inputs; the attention core of a call is timed for 1 and for 2 heads on at most 1024 query rows and
+    extrapolated linearly to all heads and rows (projections run in full).  Scaled x n_frames / 3, x blocks per level,
+    x pass counts, to the 50-step unit."""
     import torch
     from oracle import aid_cpu_port as P
     from oracle import aid_oracle as O
     from aid_amd.attn_shim import MODEL_SPECS
     spec = MODEL_SPECS[stack]
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+    try:                                                   # a container may see every host cpu but own a smaller quota
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(usable, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    torch.set_num_threads(usable)
     g = torch.Generator().manual_seed(1002)
     mode = "outer" if early.endswith("outer") else "inner"
     fused = early.startswith("fused")
@@ -205,13 +213,17 @@ def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
     t0_all = time.time()
 
     def call_time(x, ctx, w, h, md, fu, cf):
+        s_ = x.shape[1]
+        r = min(s_, 1024)
+
         def once(k):
             t0 = time.time()
-            P.processor_call(x, ctx, *w, h, md, fu, cf, only_heads=k)
+            P.processor_call(x, ctx, *w, h, md, fu, cf, only_heads=k, only_rows=r)
             return time.time() - t0
         once(1)                                          # warm the allocator / thread pool
         t1, t2 = once(1), once(2)
-        return t1 + (h - 1) * max(t2 - t1, 0.0)
+        core = max(t2 - t1, 0.0)                         # one head's attention core on r query rows
+        return (t1 - core) + h * core * (s_ / r)
 
     for (s, c, h), nblk in sorted(levels.items()):          # small levels first, the S = 4096 calls last
         cc = spec["cross_dim"]
@@ -227,10 +239,10 @@ def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
     total = n_aid * (t_aid + t_plain) + (steps - n_aid) * 2 * t_plain
     return dict(value=n_frames / (total * 50.0 / steps), unit="interpolation-frames/sec (50-step)",
                 cores=torch.get_num_threads(), kind="port",
-                sample=(f"oracle/aid_cpu_port.py (torch CPU ops, fp32, torch.get_num_threads() = {torch.get_num_threads()} of "
-                        f"{cores} host cpus): 1 transformer block (self + cross call) per resolution level in {early} and in "
-                        f"plain mode on the 3-frame sub-batch [first, middle, last], attention core timed for 1 and 2 heads and "
-                        f"extrapolated to all heads; scaled x{n_frames}/3 frames, x blocks per level, x({n_aid} AID + "
+                sample=(f"oracle/aid_cpu_port.py (torch CPU ops, fp32, torch.get_num_threads() = {torch.get_num_threads()} = the cpus this "
+                        f"process may use, of {cores} host cpus): 1 transformer block (self + cross call) per resolution level in {early} and in "
+                        f"plain mode on the 3-frame sub-batch [first, middle, last], attention core timed for 1 and 2 heads on <= 1024 "
+                        f"query rows and extrapolated to all heads / rows; scaled x{n_frames}/3 frames, x blocks per level, x({n_aid} AID + "
                         f"{2 * steps - n_aid} plain passes), x50/{steps}; measured {time.time() - t0_all:.1f} s of CPU work"))
 
 

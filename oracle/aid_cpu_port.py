@@ -31,10 +31,12 @@ def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> 
 
 @torch.no_grad()
 def processor_call(x: torch.Tensor, ctx: Optional[torch.Tensor], wq, wk, wv, wo, bo, heads: int, mode: str,
-                   fused: bool, coef: Optional[torch.Tensor], only_heads: Optional[int] = None) -> torch.Tensor:
+                   fused: bool, coef: Optional[torch.Tensor], only_heads: Optional[int] = None,
+                   only_rows: Optional[int] = None) -> torch.Tensor:
     """One attention-processor call, fp32 on the CPU.  mode: plain | outer | inner.
-    ``only_heads``: timing aid — run the attention core for the first k heads only (the other heads' output stays
-    uninitialised); the projections always run in full.  bench.py times k = 1 and k = 2 and extrapolates linearly."""
+    ``only_heads`` / ``only_rows``: timing aids — run the attention core for the first k heads / the first r query rows
+    only (the rest of the output stays uninitialised); the projections always run in full.  bench.py times k = 1 and
+    k = 2 heads on r rows and extrapolates linearly in both."""
     e = x if ctx is None else ctx
     q, k, v = x @ wq.T, e @ wk.T, e @ wv.T
     n, s, c = q.shape
@@ -44,8 +46,11 @@ def processor_call(x: torch.Tensor, ctx: Optional[torch.Tensor], wq, wk, wv, wo,
     cf = None if coef is None else coef.to(x.dtype).view(-1, 1, 1)
     for h in range(heads if only_heads is None else min(only_heads, heads)):
         qi, ki, vi = qh[:, h], kh[:, h], vh[:, h]
+        dst = out[:, h]
+        if only_rows is not None and only_rows < s:
+            qi, dst = qi[:, :only_rows], out[:, h, :only_rows]
         if mode == "plain":
-            out[:, h] = _attend(qi, ki, vi, scale)
+            dst.copy_(_attend(qi, ki, vi, scale))
             continue
         kb, ke = ki[0:1].expand_as(ki), ki[-1:].expand_as(ki)
         vb, ve = vi[0:1].expand_as(vi), vi[-1:].expand_as(vi)
@@ -55,11 +60,11 @@ def processor_call(x: torch.Tensor, ctx: Optional[torch.Tensor], wq, wk, wv, wo,
                 vb, ve = torch.cat([vi, vb], 1), torch.cat([vi, ve], 1)
             o_e = _attend(qi, ke, ve, scale)
             o_b = _attend(qi, kb, vb, scale)
-            out[:, h] = (1 - cf) * o_b + cf * o_e
+            dst.copy_((1 - cf) * o_b + cf * o_e)
         else:
             kc, vc = (1 - cf) * kb + cf * ke, (1 - cf) * vb + cf * ve
             if fused:
                 kc, vc = torch.cat([ki, kc], 1), torch.cat([vi, vc], 1)
-            out[:, h] = _attend(qi, kc, vc, scale)
+            dst.copy_(_attend(qi, kc, vc, scale))
     o = out.permute(0, 2, 1, 3).reshape(n, s, c)
     return o @ wo.T + bo

@@ -28,3 +28,26 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def _usable_cpus() -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                   # containers: every host cpu is visible, the cgroup quota is what counts
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _blas_threads_match_the_cpu_quota():
+    """The fp64 oracle runs on numpy's BLAS; on the GPU box 256 host cpus are visible but 16 are granted — 256 BLAS
+    threads make the oracle 10x slower there."""
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=_usable_cpus()):
+            yield
+    except ImportError:
+        yield

@@ -163,7 +163,7 @@ def _embs(g, cc, xl=False):
 @pytest.mark.parametrize("model,dtype,atype", [("sd15", torch.float16, "fused_inner"), ("sdxl", torch.bfloat16, "fused_outer")])
 def test_interpolate_single_end_to_end_vs_oracle_loop(model, dtype, atype):
     steps = 6 if model == "sd15" else 3
-    hip = StackDenoiser(model, dtype=dtype, device=DEV, scale_down=16 if model == "sd15" else 32, latent_hw=(8, 8))
+    hip = StackDenoiser(model, dtype=dtype, device=DEV, scale_down=16 if model == "sd15" else 64, latent_hw=(8, 8))
     cls = InterpolationStableDiffusionXLPipeline if model == "sdxl" else InterpolationStableDiffusionPipeline
     g = torch.Generator().manual_seed(9)
     l0, l1 = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
