@@ -64,7 +64,7 @@ struct AttnKParams {
     float   c2;                         // softmax_scale * log2(e)
 };
 
-__host__ __device__ constexpr bool attn_prefetch(int d, int nw) { return nw == 4 && d <= 80; }
+__host__ __device__ constexpr bool attn_prefetch(int d, int nw) { return (nw == 4 || nw == 8) && d <= 80; }
 
 // Online-softmax state of one wave: reference m (scaled log2 domain, per query = per lane), O^T blocks, and —
 // when the head dim leaves no spare padded row — the extra block whose row 0 accumulates the row sums.
@@ -890,7 +890,19 @@ static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
 
 // Four waves per workgroup for every shape: one-wave workgroups were measured slower
 // even at S = 64 (profiles/r01_attn_small_shapes.txt) — the K/V staging cost per query row quadruples.
-static int attn_nw(const AidAttnArgs&) { return 4; }
+static int attn_qb(const AidAttnArgs& a);
+
+// Waves per workgroup.  Eight waves (256 query rows sharing one K / V^T staging pass and barrier) pay only where the
+// kernel runs two waves per SIMD anyway: d = 64 OUTER (256 VGPRs) +4 % at S = 1024, +1 % at S = 4096; the three-wave PLAIN
+// kernels lose 5 - 19 % and the 77-key cross-attention launches 4 - 8 % (profiles/r02_attn_notes.txt).  Built for d <= 80;
+// development knob AID_ATTN_NW = 4 / 8.
+static int attn_nw(const AidAttnArgs& a) {
+    const char* env = getenv("AID_ATTN_NW");
+    if (a.d > 80) return 4;
+    if (a.d == 40 && a.mode == AID_MODE_PLAIN && attn_qb(a) == 2) return 4;
+    if (env) return atoi(env) == 8 ? 8 : 4;
+    return (a.d == 64 && a.mode == AID_MODE_OUTER && a.l >= 256) ? 8 : 4;
+}
 
 // query blocks (of 32 rows) per wave.  Measured (profiles/r02_attn_notes.txt, tools/kbench_attn_ab.py): 64 rows per wave
 // pays only where the kernel still fits two waves per SIMD — d = 40 PLAIN (254 VGPRs, +4 % at S = 4096); every other
@@ -923,6 +935,10 @@ static hipError_t launch_nw(AttnKParams& p, hipStream_t stream) {
     }
     p.nqb = (p.a.s + 127) / 128;
     constexpr bool CAN_PIPE = D == 40 || (D == 64 && MODE == AID_MODE_PLAIN);
+    if (D <= 80 && attn_nw(p.a) == 8) {
+        p.nqb = (p.a.s + 255) / 256;
+        return launch_variant<T, D, MODE, (D <= 80) ? 8 : 4, 1, false>(p, stream);
+    }
     if (CAN_PIPE && attn_pipe(p.a)) return launch_variant<T, D, MODE, 4, 1, CAN_PIPE>(p, stream);
     return launch_variant<T, D, MODE, 4, 1, false>(p, stream);
 }
@@ -999,7 +1015,7 @@ const char* attn_variant_name(const AidAttnArgs& a) {
     if (attn_qb(a) == 2)
         snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d,qb2>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
                  modes[a.mode], attn_nw(a));
-    else if (attn_pipe(a))
+    else if (attn_nw(a) != 8 && attn_pipe(a))
         snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d,pipe>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
                  modes[a.mode], attn_nw(a));
     else
