@@ -18,6 +18,7 @@ from .processors import (HipAttnProcessor, HipIPAdapterAttnProcessor, InnerInter
                          deactivate_aid, load_aid, load_aid_ip_adapter)
 from .attn_shim import AttnShim, AttnStackUNet, IPAdapterShim
 from . import ops, _lib, sequence, loop, dist, prior, pipelines
+from .prior import BetaPriorExplorer, BetaPriorPipeline
 from .pipelines import (DDIMSchedulerLite, InterpolationStableDiffusionPipeline,
                         InterpolationStableDiffusionXLPipeline, StackDenoiser)
 
@@ -27,6 +28,6 @@ __all__ = [
     "OuterInterpolatedIPAttnProcessor", "InnerInterpolatedIPAttnProcessor", "ScaleControlIPAttnProcessor",
     "HipAttnProcessor", "HipIPAdapterAttnProcessor", "load_aid", "load_aid_ip_adapter", "activate_aid", "deactivate_aid",
     "AttnShim", "AttnStackUNet", "IPAdapterShim", "ops",
-    "InterpolationStableDiffusionPipeline", "InterpolationStableDiffusionXLPipeline", "DDIMSchedulerLite", "StackDenoiser",
+    "BetaPriorPipeline", "BetaPriorExplorer", "InterpolationStableDiffusionPipeline", "InterpolationStableDiffusionXLPipeline", "DDIMSchedulerLite", "StackDenoiser",
 ]
 __version__ = "0.1.0"

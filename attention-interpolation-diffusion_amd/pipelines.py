@@ -325,10 +325,13 @@ class InterpolationStableDiffusionPipeline:
                     beta: Optional[float] = None, guidance_scale: Optional[float] = None,
                     # build-specific
                     embeds_start=None, embeds_end=None, embeds_guide=None, batched_cfg: bool = True,
-                    output_type: str = "np"):
+                    output_type: str = "np", coef: Optional[Sequence[float]] = None):
         """gradio_src/pipeline_interpolated_stable_diffusion.py:163-304 with the root pipelines' warm-up count
         (``i < int(T * warmup_ratio)`` with 0-based ``i``).  ``late`` must be "self" (plain
-        attention) or one of the AID modes.  ``batched_cfg``: the two passes of a step run as one UNet call."""
+        attention) or one of the AID modes.  ``batched_cfg``: the two passes of a step run as one UNet call.
+        ``coef`` (build-specific, ``[0, t_1, ..., 1]``): render the frames at THESE coefficients the way
+        ``interpolate_single(t_k)`` would — latents slerp'd and embeddings lerp'd at ``t_k``, attention coefficient
+        ``t_k`` — in one N-frame run (the Beta-prior exploration fills several gaps per run with it, prior.py)."""
         if early not in EARLY_MODES or (late != "self" and late not in EARLY_MODES):
             raise ValueError(f"early / late must be in {EARLY_MODES} (late also 'self')")
         gs = self.default_guidance_scale if guidance_scale is None else guidance_scale
@@ -343,6 +346,18 @@ class InterpolationStableDiffusionPipeline:
                                  uncond_guide=None if guide is None else guide[1][0],
                                  num_inference_steps=num_inference_steps, alpha=alpha, beta=beta)
         pooled = self._pooled_sequence(cond_s, cond_e, unc_s, unc_e, guide, size)
+        if coef is not None:
+            ts = [float(t) for t in coef]
+            if len(ts) != size or ts[0] != 0.0 or ts[-1] != 1.0:
+                raise ValueError("coef must be [0, ..., 1] with `size` entries")
+            l0, l1 = latent_start.to(dev, dtype), latent_end.to(dev, dtype)
+            batch.latents = torch.cat([l0] + [slerp(l0, l1, t) for t in ts[1:-1]] + [l1], dim=0)
+            batch.coef = torch.tensor(ts, dtype=torch.float32)
+            if guide is None:
+                batch.cond = linear_interpolation(cond_s[0], cond_e[0], ts=ts)
+                batch.uncond = linear_interpolation(unc_s[0], unc_e[0], ts=ts)
+                if pooled is not None:
+                    pooled = (linear_interpolation(cond_s[1], cond_e[1], ts=ts), linear_interpolation(unc_s[1], unc_e[1], ts=ts))
         self.scheduler.set_timesteps(num_inference_steps, device=dev)
         warmup_steps = int(num_inference_steps * warmup_ratio)
         procs = {}

@@ -170,3 +170,70 @@ class BetaPriorExplorer:
         idxs = extract_uniform_points_plus(features, interpolation_size, self.distance)
         self.frames, self.ds, self.xs, self.alpha, self.beta_param = frames, ds, xs, alpha, beta_param   # prior.py:332-338
         return [frames[i] for i in idxs]
+
+
+class BetaPriorPipeline:
+    """The reference's ``BetaPriorPipeline`` (prior.py:12-340) over this package's pipeline classes: same constructor
+    shape (``pipe``, ``model_ID``) and methods (``_compute_clip``, ``_get_feature``, ``explore_with_beta``,
+    ``generate_interpolation``; attributes ``images / ds / xs / alpha / beta_param`` after a run, :332-338).
+
+    Feature extractor: ``model`` = anything with ``get_image_features(pixel_values) -> [B, D]`` (transformers'
+    ``CLIPModel`` when its weights are available — third-party; ``model_ID`` is tried through ``from_pretrained`` only if
+    no model is given) plus an optional ``preprocess``; features and the cosine distances stay on the device the frames
+    are on (the reference moves every frame through CPU PIL preprocessing).
+    Rendering: ``pipe.interpolate_single(t, ...)`` per new point like the reference, or — ``batch`` > 1 — one N-frame
+    ``pipe.interpolate`` run over ``[0, *ts, 1]`` filling several gaps at once (the processors take any coefficient vector).
+    """
+
+    def __init__(self, pipe, model_ID: str = "openai/clip-vit-base-patch32", model=None, preprocess=None):
+        if model is None:
+            from transformers import CLIPImageProcessor, CLIPModel      # needs the checkpoint on disk (no network here)
+            model = CLIPModel.from_pretrained(model_ID)
+            preprocess = preprocess or CLIPImageProcessor.from_pretrained(model_ID)
+        self.model, self.preprocess, self.pipe = model, preprocess, pipe
+
+    def _compute_clip(self, embedding_a, embedding_b):
+        return clip_distance(embedding_a, embedding_b)
+
+    @torch.no_grad()
+    def _get_feature(self, image):
+        if self.preprocess is not None:
+            image = self.preprocess(image)
+        if not torch.is_tensor(image):
+            image = torch.as_tensor(np.asarray(image))
+        if image.ndim == 3:
+            image = image[None]
+        return self.model.get_image_features(image)
+
+    def _render(self, ts, prompt_start, prompt_end, negative_prompt, latent_start, latent_end, num_inference_steps, kw):
+        """Frames at ``[0, *ts, 1]``: batch-3 ``interpolate_single`` for one point (the reference's call, prior.py:94-104),
+        an N-frame ``interpolate`` with the coefficient vector for several."""
+        if len(ts) == 1:
+            out = self.pipe.interpolate_single(ts[0], prompt_start=prompt_start, prompt_end=prompt_end,
+                                               negative_prompt=negative_prompt, latent_start=latent_start,
+                                               latent_end=latent_end, num_inference_steps=num_inference_steps, **kw)
+            frames = out["images"] if isinstance(out, dict) else out.images
+        else:
+            frames = self.pipe.interpolate(latent_start, latent_end, prompt_start, prompt_end,
+                                           negative_prompt=negative_prompt, size=len(ts) + 2,
+                                           num_inference_steps=num_inference_steps, coef=[0.0] + list(ts) + [1.0], **kw)
+        frames = [frames[i] for i in range(len(ts) + 2)]
+        return frames, [self._get_feature(f) for f in frames]
+
+    def explore_with_beta(self, prompt_start, prompt_end, negative_prompt, latent_start, latent_end,
+                          num_inference_steps=28, exploration_size=16, init_alpha=3, init_beta=3, uniform=False,
+                          batch: int = 1, **kwargs):
+        kwargs.pop("early", None)                      # accepted and ignored like the reference (SURVEY.md App. D4)
+        ex = BetaPriorExplorer(lambda ts: self._render(ts, prompt_start, prompt_end, negative_prompt, latent_start,
+                                                       latent_end, num_inference_steps, kwargs), self._compute_clip)
+        return ex.explore(exploration_size, init_alpha, init_beta, uniform=uniform, batch=batch)
+
+    def generate_interpolation(self, prompt_start, prompt_end, negative_prompt, latent_start, latent_end,
+                               num_inference_steps=28, exploration_size=16, init_alpha=3, init_beta=3,
+                               interpolation_size=7, uniform=False, **kwargs):
+        images, features, ds, xs, alpha, beta_param = self.explore_with_beta(
+            prompt_start, prompt_end, negative_prompt, latent_start, latent_end, num_inference_steps, exploration_size,
+            init_alpha, init_beta, uniform=uniform, **kwargs)
+        idxs = extract_uniform_points_plus(features, interpolation_size, self._compute_clip)
+        self.images, self.ds, self.xs, self.alpha, self.beta_param = images, ds, xs, alpha, beta_param
+        return [images[i] for i in idxs]

@@ -53,3 +53,38 @@ def test_batched_exploration_fills_several_gaps_per_run():
                                [float(P.clip_distance(features[i], features[i + 1])) for i in range(11)], atol=1e-7)
     out = ex.generate_interpolation(interpolation_size=5, exploration_size=10, batch=2)
     assert len(out) == 5 and out[0] == 0.0 and out[-1] == 1.0 and out == sorted(out)
+
+
+def test_beta_prior_pipeline_facade_over_the_pipeline_classes():
+    """BetaPriorPipeline (prior.py:12-340 surface) over InterpolationStableDiffusionPipeline with a recording stub UNet and a
+    stand-in feature extractor: batch = 1 renders one interpolate_single per point like the reference, batch = 3 fills
+    several gaps per N-frame run; both leave images / ds / xs / alpha / beta_param behind (:332-338)."""
+    import torch
+    import aid_amd
+    from test_pipelines import RecordingUNet
+    from aid_amd.pipelines import DDIMSchedulerLite, InterpolationStableDiffusionPipeline
+
+    class Feat:
+        def get_image_features(self, x):
+            v = x.float().reshape(x.shape[0], -1)
+            return torch.cat([v[:, :8], v[:, :8].sin()], dim=1)
+
+    g = torch.Generator().manual_seed(3)
+    l0, l1 = torch.randn(1, 4, 4, 4, generator=g), torch.randn(1, 4, 4, 4, generator=g)
+    mk = lambda: (torch.randn(1, 7, 12, generator=g), torch.randn(1, 7, 12, generator=g))     # noqa: E731
+    es, ee = mk(), mk()
+    runs = {}
+    for batch in (1, 3):
+        unet = RecordingUNet()
+        pipe = InterpolationStableDiffusionPipeline(unet, DDIMSchedulerLite())
+        pipe.load_aid(t=0.5, is_fused=True, atype="fused_outer")
+        bp = aid_amd.BetaPriorPipeline(pipe, model=Feat())
+        frames = bp.generate_interpolation(None, None, None, l0, l1, num_inference_steps=4, exploration_size=8,
+                                           interpolation_size=5, batch=batch, embeds_start=es, embeds_end=ee,
+                                           output_type="latent", early="fused_outer")
+        assert len(frames) == 5 and len(bp.xs) == 8 and bp.xs[0] == 0.0 and bp.xs[-1] == 1.0
+        assert bp.xs == sorted(bp.xs) and len(bp.ds) == 7 and bp.alpha > 0 and bp.beta_param > 0
+        runs[batch] = [c["n"] for c in unet.calls]
+    assert set(runs[1]) == {3}                          # batch-3 interpolate_single runs only
+    assert max(runs[3]) > 3                             # N-frame runs ([cond ; uncond] batched) fill several gaps
+    assert len(runs[3]) < len(runs[1])
