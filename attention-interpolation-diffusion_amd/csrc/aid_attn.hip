@@ -476,10 +476,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         // further ahead than V^T: iteration i stages K(i+2) and V^T(i) (loads issued at its start, written in phase B),
         // one barrier per iteration.
         auto run_pipe = [&](int nfp) __attribute__((always_inline)) {
-            static_assert(!PIPE || (QB == 1 && PREFETCH), "pipelined loop: one query block per wave, register staging");
-            constexpr int NPV = 4 * (NDB + (XL ? 1 : 0));       // MFMAs of one PV
-            constexpr int NQM = 2 * NQK;                        // MFMAs of one QK
-            constexpr int NOP = 32;                             // VALU micro-ops per phase
+            static_assert(!PIPE || PREFETCH, "pipelined loop: register staging");
+            constexpr int NDX = NDB + (XL ? 1 : 0);             // O^T blocks incl. the row-sum block
+            constexpr int NPV = 4 * NDX * QB;                   // MFMAs of one PV (all query blocks of the wave)
+            constexpr int NQM = 2 * NQK * QB;                   // MFMAs of one QK
+            constexpr int NOP = 32 * QB;                        // VALU micro-ops per phase
             auto ld_k = [&](int t_) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < NKC; ++i)
@@ -500,115 +501,131 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 if (NVC * NT != VCH && id >= VCH) return;
                 *reinterpret_cast<T8*>(Vs + buf * DV * VLD + (id / (KT / 8)) * VLD + (id % (KT / 8)) * 8) = rv[PREFETCH ? i : 0];
             };
-            auto cneg_of = [&]() __attribute__((always_inline)) {
+            auto cneg_of = [&](int j) __attribute__((always_inline)) {
                 f32x16 c;
                 if (PERSIST_C) {
-                    c = st.cn[0];
+                    c = st.cn[j];
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) c[r] = -st.m[0];
+                    for (int r = 0; r < 16; ++r) c[r] = -st.m[j];
                 }
                 return c;
             };
-            // QK of the tile in LDS buffer `buf`, program order (prologue and the rare slow path)
-            auto qk_plain = [&](int buf, f32x16 (&s_)[2]) __attribute__((always_inline)) {
-                const f32x16 cneg = cneg_of();
+            typedef f32x16 Sc[QB][2];
+            typedef T8 Pf[QB][4];
+            // QK of the tile in LDS buffer `buf`, program order (prologue)
+            auto qk_plain = [&](int buf, Sc& s_) __attribute__((always_inline)) {
                 const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
 #pragma unroll
                 for (int ks = 0; ks < NQK; ++ks) {
-                    s_[0] = mfma32(*reinterpret_cast<const T8*>(kt + ks * 16), qf[0][ks], ks ? s_[0] : cneg);
-                    s_[1] = mfma32(*reinterpret_cast<const T8*>(kt + 32 * KLD + ks * 16), qf[0][ks], ks ? s_[1] : cneg);
+                    const T8 f0 = *reinterpret_cast<const T8*>(kt + ks * 16);
+                    const T8 f1 = *reinterpret_cast<const T8*>(kt + 32 * KLD + ks * 16);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        s_[j][0] = mfma32(f0, qf[j][ks], ks ? s_[j][0] : cneg_of(j));
+                        s_[j][1] = mfma32(f1, qf[j][ks], ks ? s_[j][1] : cneg_of(j));
+                    }
                 }
             };
-            // VALU micro-ops.  Phase A, op k: 0..15 = the max3 chain over S, 16..31 = exp of S[0][k-16] in place.
-            auto op_a = [&](int k, f32x16 (&s_)[2], float& mx) __attribute__((always_inline)) {
-                // the empty asm pins the op where it is written: without it LLVM sinks the (pure) chain to its first use
-                // behind the MFMAs and the interleave is gone
-                if (k < 16) {
-                    if (k == 0) mx = fmaxf(s_[0][0], s_[0][1]);
-                    else        mx = fmaxf(fmaxf(mx, s_[k >> 3][(2 * k) & 15]), s_[k >> 3][(2 * k + 1) & 15]);
-                    asm volatile("" : "+v"(mx));
+            // VALU micro-ops, the wave's query blocks interleaved (op k belongs to block k % QB).  Phase A, step u = k / QB:
+            // 0..15 = the max3 chain over S, 16..31 = exp of S[0][u-16] in place.
+            // the empty asm pins the op where it is written: without it LLVM sinks the (pure) chain to its first use
+            // behind the MFMAs and the interleave is gone
+            auto op_a = [&](int k, Sc& s_, float (&mx)[QB]) __attribute__((always_inline)) {
+                const int j = k % QB, u = k / QB;
+                if (u < 16) {
+                    if (u == 0) mx[j] = fmaxf(s_[j][0][0], s_[j][0][1]);
+                    else        mx[j] = fmaxf(fmaxf(mx[j], s_[j][u >> 3][(2 * u) & 15]), s_[j][u >> 3][(2 * u + 1) & 15]);
+                    asm volatile("" : "+v"(mx[j]));
                 } else {
-                    float e = __builtin_amdgcn_exp2f(s_[0][k - 16]);
+                    float e = __builtin_amdgcn_exp2f(s_[j][0][u - 16]);
                     asm volatile("" : "+v"(e));
-                    s_[0][k - 16] = e;
+                    s_[j][0][u - 16] = e;
                 }
             };
-            // Phase B, op k: 0..7 = cvt_pk of block 0 (exponentiated in phase A) -> P[0..1]; 8..23 = exp of S[1][k-8];
+            // Phase B, step u: 0..7 = cvt_pk of block 0 (exponentiated in phase A) -> P[0..1]; 8..23 = exp of S[1][u-8];
             // 24..31 = cvt_pk of block 1 -> P[2..3]
-            auto op_b = [&](int k, f32x16 (&s_)[2], T8 (&p_)[4]) __attribute__((always_inline)) {
+            auto op_b = [&](int k, Sc& s_, Pf& p_) __attribute__((always_inline)) {
                 typedef typename Vec<T>::v2 T2;
-                if (k < 8 || k >= 24) {
-                    const int b = k < 8 ? 0 : 1, j = k < 8 ? k : k - 24;          // pair j of block b: elements 2j, 2j+1
+                const int j = k % QB, u = k / QB;
+                if (u < 8 || u >= 24) {
+                    const int b = u < 8 ? 0 : 1, w = u < 8 ? u : u - 24;          // pair w of key block b: elements 2w, 2w+1
                     f32x2 v2;
-                    v2[0] = s_[b][2 * j];
-                    v2[1] = s_[b][2 * j + 1];
+                    v2[0] = s_[j][b][2 * w];
+                    v2[1] = s_[j][b][2 * w + 1];
                     T2 c2 = __builtin_convertvector(v2, T2);
                     asm volatile("" : "+v"(c2));
-                    p_[2 * b + (j >> 2)][2 * (j & 3)] = c2[0];
-                    p_[2 * b + (j >> 2)][2 * (j & 3) + 1] = c2[1];
+                    p_[j][2 * b + (w >> 2)][2 * (w & 3)] = c2[0];
+                    p_[j][2 * b + (w >> 2)][2 * (w & 3) + 1] = c2[1];
                 } else {
-                    float e = __builtin_amdgcn_exp2f(s_[1][k - 8]);
+                    float e = __builtin_amdgcn_exp2f(s_[j][1][u - 8]);
                     asm volatile("" : "+v"(e));
-                    s_[1][k - 8] = e;
+                    s_[j][1][u - 8] = e;
                 }
             };
-            // head-room slow path for tile i (first tile of the wave, or a score out-grew the storage type's head-room): S(i)
-            // was partly exponentiated in place, so it is recomputed from K(i) (still in LDS buffer i & 1), the reference is
-            // moved to the row maximum, O is rescaled (PV(i-1) is complete) and block 0 is exponentiated again
             // S of tile t straight from global memory in fragment layout (slow path only: the LDS buffer that held K(t) may
             // already be receiving K(t+2) from a faster wave)
-            auto qk_global = [&](int t_, f32x16 (&s_)[2]) __attribute__((always_inline)) {
-                const f32x16 cneg = cneg_of();
+            auto qk_global = [&](int t_, Sc& s_) __attribute__((always_inline)) {
                 const T* kg = k0 + (int64_t)(t_ * KT + krow) * a.ldk + hi * 8;
 #pragma unroll
                 for (int ks = 0; ks < NQK; ++ks) {
                     const bool in = ks * 16 + hi * 8 < D;
                     const T8 f0 = in ? *reinterpret_cast<const T8*>(kg + ks * 16) : zero8<T>();
                     const T8 f1 = in ? *reinterpret_cast<const T8*>(kg + (int64_t)32 * a.ldk + ks * 16) : zero8<T>();
-                    s_[0] = mfma32(f0, qf[0][ks], ks ? s_[0] : cneg);
-                    s_[1] = mfma32(f1, qf[0][ks], ks ? s_[1] : cneg);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) {
+                        s_[j][0] = mfma32(f0, qf[j][ks], ks ? s_[j][0] : cneg_of(j));
+                        s_[j][1] = mfma32(f1, qf[j][ks], ks ? s_[j][1] : cneg_of(j));
+                    }
                 }
             };
-            auto slow = [&](int i, f32x16 (&s_)[2]) __attribute__((always_inline)) {
+            // head-room slow path for tile i (first tile of the wave, or a score out-grew the storage type's head-room): S(i)
+            // was partly exponentiated in place, so it is recomputed, the reference is moved to the row maximum, O is
+            // rescaled (PV(i-1) is complete) and block 0 is exponentiated again
+            auto slow = [&](int i, Sc& s_) __attribute__((always_inline)) {
                 qk_global(i, s_);
-                float xm = fmaxf(s_[0][0], s_[0][1]);
 #pragma unroll
-                for (int k = 1; k < 16; ++k) xm = fmaxf(fmaxf(xm, s_[k >> 3][(2 * k) & 15]), s_[k >> 3][(2 * k + 1) & 15]);
-                const float rowmax = max_halves(xm);
-                const float shift = st.fresh ? rowmax : fmaxf(rowmax, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-shift);
-                st.m[0] += shift;
+                for (int j = 0; j < QB; ++j) {
+                    float xm = fmaxf(s_[j][0][0], s_[j][0][1]);
+#pragma unroll
+                    for (int k = 1; k < 16; ++k) xm = fmaxf(fmaxf(xm, s_[j][k >> 3][(2 * k) & 15]), s_[j][k >> 3][(2 * k + 1) & 15]);
+                    const float rowmax = max_halves(xm);
+                    const float shift = st.fresh ? rowmax : fmaxf(rowmax, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-shift);
+                    st.m[j] += shift;
+                    if (PERSIST_C) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st.cn[j][r] = -st.m[j];
+                        asm volatile("" : "+v"(st.cn[j]));
+                    }
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st.o[j][d][r] *= alpha;
+                    if (XL) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st.ol[j][r] *= alpha;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s_[j][0][r] = __builtin_amdgcn_exp2f(s_[j][0][r] - shift);
+                        s_[j][1][r] -= shift;
+                    }
+                }
                 st.fresh = false;
-                if (PERSIST_C) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st.cn[0][r] = -st.m[0];
-                    asm volatile("" : "+v"(st.cn[0]));
-                }
-#pragma unroll
-                for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st.o[0][d][r] *= alpha;
-                if (XL) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st.ol[0][r] *= alpha;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s_[0][r] = __builtin_amdgcn_exp2f(s_[0][r] - shift);
-                    s_[1][r] -= shift;
-                }
             };
             // one iteration; HAS_PV: PV(i-1) exists, HAS_KLD: K(i+2) exists, HAS_QK: tile i+1 exists
-            auto iter = [&](auto has_pv_t, auto has_kld_t, auto has_qk_t, int i, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2],
-                            T8 (&p_prev)[4], T8 (&p_cur)[4]) __attribute__((always_inline)) {
+            auto iter = [&](auto has_pv_t, auto has_kld_t, auto has_qk_t, int i, Sc& s_cur, Sc& s_nxt, Pf& p_prev,
+                            Pf& p_cur) __attribute__((always_inline)) {
                 constexpr bool HAS_PV = decltype(has_pv_t)::value, HAS_KLD = decltype(has_kld_t)::value,
                                HAS_QK = decltype(has_qk_t)::value;
                 const int bc = i & 1;
                 if (HAS_KLD) ld_k(i + 2);
                 ld_v(i);
                 // ---------------- phase A ----------------
-                float mx = 0.f;
+                float mx[QB];
+#pragma unroll
+                for (int j = 0; j < QB; ++j) mx[j] = 0.f;
                 if (HAS_PV) {
                     const T* vt = Vs + (bc ^ 1) * DV * VLD + l31 * VLD + hi * 8;
                     T8 vf[2][NDB];
@@ -623,25 +640,33 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                                 vf[(kk + 1) & 1][d] = *reinterpret_cast<const T8*>(vt + d * 32 * VLD + (kk + 1) * 16);
                         }
 #pragma unroll
-                        for (int d = 0; d < NDB + (XL ? 1 : 0); ++d) {
-                            if (d < NDB) st.o[0][d] = mfma32(vf[kk & 1][d], p_prev[kk], st.o[0][d]);
-                            else         st.ol[0] = mfma32(onesf, p_prev[kk], st.ol[0]);
-                            __builtin_amdgcn_sched_barrier(0);
-                            const int g = kk * (NDB + (XL ? 1 : 0)) + d;
+                        for (int d = 0; d < NDX; ++d) {
 #pragma unroll
-                            for (int k = g * NOP / NPV; k < (g + 1) * NOP / NPV; ++k) op_a(k, s_cur, mx);
-                            __builtin_amdgcn_sched_barrier(0);
+                            for (int j = 0; j < QB; ++j) {
+                                if (d < NDB) st.o[j][d] = mfma32(vf[kk & 1][d], p_prev[j][kk], st.o[j][d]);
+                                else         st.ol[j] = mfma32(onesf, p_prev[j][kk], st.ol[j]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                const int g = (kk * NDX + d) * QB + j;
+#pragma unroll
+                                for (int k = g * NOP / NPV; k < (g + 1) * NOP / NPV; ++k) op_a(k, s_cur, mx);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < NOP; ++k) op_a(k, s_cur, mx);
                 }
-                if (st.fresh || __any(mx > XTH)) slow(i, s_cur);
+                float mall = mx[0];
+#pragma unroll
+                for (int j = 1; j < QB; ++j) mall = fmaxf(mall, mx[j]);
+                if (st.fresh || __any(mall > XTH)) slow(i, s_cur);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---------------- phase B ----------------
                 if (HAS_QK) {
-                    const f32x16 cneg = cneg_of();
+                    f32x16 cneg[QB];
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) cneg[j] = cneg_of(j);
                     const T* kt = Ks + (bc ^ 1) * KT * KLD + krow * KLD + hi * 8;
                     T8 kf[2][2];
                     kf[0][0] = *reinterpret_cast<const T8*>(kt);
@@ -655,18 +680,21 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     for (int ks = 0; ks < NQK; ++ks) {
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
-                            s_nxt[b] = mfma32(kf[ks & 1][b], qf[0][ks], ks ? s_nxt[b] : cneg);
-                            __builtin_amdgcn_sched_barrier(0);
-                            const int g = 2 * ks + b;
 #pragma unroll
-                            for (int k = g * NOP / NQM; k < (g + 1) * NOP / NQM; ++k) op_b(k, s_cur, p_cur);
-                            // the staged tiles go to LDS in the last gaps (their loads were issued a phase and a half ago)
-                            if (g >= NQM - NKC - NVC) {
-                                const int w = g - (NQM - NKC - NVC);
-                                if (w < NKC) { if (HAS_KLD) wr_k(bc, w); }
-                                else         wr_v(bc, w - NKC);
+                            for (int j = 0; j < QB; ++j) {
+                                s_nxt[j][b] = mfma32(kf[ks & 1][b], qf[j][ks], ks ? s_nxt[j][b] : cneg[j]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                const int g = (2 * ks + b) * QB + j;
+#pragma unroll
+                                for (int k = g * NOP / NQM; k < (g + 1) * NOP / NQM; ++k) op_b(k, s_cur, p_cur);
+                                // the staged tiles go to LDS in the last gaps (their loads were issued a phase and a half ago)
+                                if (g >= NQM - NKC - NVC) {
+                                    const int w = g - (NQM - NKC - NVC);
+                                    if (w < NKC) { if (HAS_KLD) wr_k(bc, w); }
+                                    else         wr_v(bc, w - NKC);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
                             }
-                            __builtin_amdgcn_sched_barrier(0);
                         }
                         if (ks + 2 < NQK) {
                             kf[ks & 1][0] = *reinterpret_cast<const T8*>(kt + (ks + 2) * 16);
@@ -684,8 +712,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             };
             static_assert(NKC + NVC <= 2 * NQK, "staging writes must fit the gaps of phase B");
 
-            f32x16 sA[2], sB[2];
-            T8 pA[4], pB[4];
+            Sc sA, sB;
+            Pf pA, pB;
             // prologue: K(0), K(1) to LDS, S(0)
             ld_k(0);
 #pragma unroll
@@ -710,9 +738,15 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                    for (int d = 0; d < NDB; ++d)
-                        st.o[0][d] = mfma32(*reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16), pA[kk], st.o[0][d]);
-                    if (XL) st.ol[0] = mfma32(onesf, pA[kk], st.ol[0]);
+                    for (int d = 0; d < NDB; ++d) {
+                        const T8 vf = *reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16);
+#pragma unroll
+                        for (int j = 0; j < QB; ++j) st.o[j][d] = mfma32(vf, pA[j][kk], st.o[j][d]);
+                    }
+                    if (XL) {
+#pragma unroll
+                        for (int j = 0; j < QB; ++j) st.ol[j] = mfma32(onesf, pA[j][kk], st.ol[j]);
+                    }
                 }
             }
             __syncthreads();
@@ -899,7 +933,7 @@ static int attn_qb(const AidAttnArgs& a);
 static int attn_nw(const AidAttnArgs& a) {
     const char* env = getenv("AID_ATTN_NW");
     if (a.d > 80) return 4;
-    if (a.d == 40 && a.mode == AID_MODE_PLAIN && attn_qb(a) == 2) return 4;
+    if (attn_qb(a) >= 2) return 4;
     if (env) return atoi(env) == 8 ? 8 : 4;
     return (a.d == 64 && a.mode == AID_MODE_OUTER && a.l >= 256) ? 8 : 4;
 }
