@@ -25,6 +25,7 @@
 #include "aid_kernels.hpp"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace aid {
 
@@ -598,9 +599,33 @@ struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, const int n_big) {
+__global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, const int n_big, const GemmSide sd) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int b = blockIdx.x;
+    if ((int)blockIdx.x < sd.pad_tiles) {                          // side problems first: their long K loops start at once
+        const int u = blockIdx.x;
+        if (u >= sd.tiles) return;
+        int pi = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i < sd.n && u >= sd.tile_start[i]) pi = i;
+        const GemmDesc& P = sd.p[pi];
+        int rem = u - sd.tile_start[pi];
+        const int tiles_n = (P.n + 127) / 128, per_batch = ((P.m + 127) / 128) * tiles_n;
+        const int batch = rem / per_batch;
+        rem -= batch * per_batch;
+        const int m0 = (rem / tiles_n) * 128, n0 = (rem % tiles_n) * 128;
+        const T* A = reinterpret_cast<const T*>(P.a) + (int64_t)batch * P.stride_a;
+        const T* B = reinterpret_cast<const T*>(P.b) + (int64_t)batch * P.stride_b;
+        T* C = reinterpret_cast<T*>(P.c) + (int64_t)batch * P.stride_c;
+        Engine<T, 128, 128, 64, 2, 2, 4> e;
+        e.init(smem_raw);
+        e.set_tile(P, A, B, m0, n0);
+        e.zero_acc();
+        e.mac(0, P.k / 64);
+        e.store_tile(P, C, m0, n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)batch * P.stride_c : nullptr);
+        return;
+    }
+    const int b = blockIdx.x - sd.pad_tiles;
     if (b < n_big) {
         const TileCoord tc = locate_pos<256, 256>(g, xcd_remap(b, n_big));
         const GemmDesc& P = g.p[tc.p];
@@ -615,7 +640,7 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr);
     } else {
         const int u = b - n_big;                                   // n_big is a multiple of 8: u % 8 is still the XCD
-        const int n_rest = (gridDim.x - n_big) >> 2;
+        const int n_rest = ((int)gridDim.x - sd.pad_tiles - n_big) >> 2;
         const int quad = u / n_rest, t = u - quad * n_rest;        // quadrant-major: equal quadrants are neighbours
         TileCoord tc = locate_pos<256, 256>(g, n_big + xcd_remap(t, n_rest));
         const GemmDesc& P = g.p[tc.p];
@@ -720,7 +745,7 @@ static PpPlan plan_pp(GemmGroup& g, int ncu, int nk) {
 }
 
 template <typename T>
-static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl) {
+static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl, const GemmSide& sd) {
     static PerDevice<bool> attr_set;
     if (pl.tiles <= 0) return hipSuccess;
     if (plan_tiles(g, 256, 256) != pl.tiles) return hipErrorInvalidValue;      // g.tile_start must be in 256 x 256 units
@@ -732,8 +757,8 @@ static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl) 
         if (e != hipSuccess) return e;
         *done = true;
     }
-    hipLaunchKernelGGL(aid_gemm_nt_pp_kernel<T>, dim3(pl.n_big + pl.n_small), dim3(512), PingPong<T>::SMEM, stream, g,
-                       pl.n_big);
+    hipLaunchKernelGGL(aid_gemm_nt_pp_kernel<T>, dim3(sd.pad_tiles + pl.n_big + pl.n_small), dim3(512), PingPong<T>::SMEM,
+                       stream, g, pl.n_big, sd);
     return hipGetLastError();
 }
 
@@ -761,6 +786,52 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** var
     if (ncu <= 0) return hipErrorInvalidDevice;
     bool pp = false;
     PpPlan pl = {};
+    GemmSide sd;
+    memset(&sd, 0, sizeof(sd));
+    if (g.interleave && g.n_problems > 1 && force != 7) {
+        // K loops differ: if a few short problems (<= 15 % of the flops) sit next to main problems of ONE K that the
+        // ping-pong engine would win, run the short ones as side tiles of the ping-pong launch
+        double fl[AID_GEMM_MAX_PROBLEMS], tot = 0, best = -1;
+        int kmain = 0;
+        for (int i = 0; i < g.n_problems; ++i) {
+            fl[i] = 2.0 * g.p[i].m * g.p[i].n * g.p[i].k * g.p[i].batch;
+            tot += fl[i];
+            if (fl[i] > best) { best = fl[i]; kmain = g.p[i].k; }
+        }
+        GemmGroup gm;
+        memset(&gm, 0, sizeof(gm));
+        double side_fl = 0;
+        int ns = 0, st = 0;
+        bool ok = true;
+        for (int i = 0; i < g.n_problems; ++i) {
+            if (g.p[i].k == kmain) {
+                gm.p[gm.n_problems++] = g.p[i];
+            } else if (ns < 4) {
+                sd.p[ns] = g.p[i];
+                sd.tile_start[ns] = st;
+                st += ((g.p[i].m + 127) / 128) * ((g.p[i].n + 127) / 128) * g.p[i].batch;
+                side_fl += fl[i];
+                ++ns;
+            } else {
+                ok = false;
+            }
+        }
+        for (int i = ns; i <= 4; ++i) sd.tile_start[i] = st;
+        if (ok && ns > 0 && side_fl <= 0.15 * tot && st <= ncu) {
+            const int nk = kmain / 64;
+            const int t128 = plan_tiles(gm, 128, 128);
+            const PpPlan plm = plan_pp(gm, ncu, nk);
+            const double r128 = 0.5 * (double)((2 * t128 + 2 * ncu - 1) / (2 * ncu));
+            if (5.0 + plm.rounds * (6.0 + 1.62 * nk) < 0.95 * (3.0 + r128 * (4.1 + 1.09 * nk)) || force == 31) {
+                sd.n = ns;
+                sd.tiles = st;
+                sd.pad_tiles = (st + 7) / 8 * 8;
+                if (variant) *variant = plm.n_small ? "pingpong256+tail128+side128" : "pingpong256+side128";
+                return launch_pp<T>(gm, stream, plm, sd);
+            }
+        }
+        memset(&sd, 0, sizeof(sd));
+    }
     if (!g.interleave && g.n_problems > 0) {
         const int nk = g.p[0].k / 64;
         const int t128 = plan_tiles(g, 128, 128);
@@ -773,7 +844,7 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** var
     }
     if (force == 7) pp = false;
     if (variant) *variant = !pp ? "lockstep128" : pl.n_small ? "pingpong256+tail128" : "pingpong256";
-    if (pp) return launch_pp<T>(g, stream, pl);
+    if (pp) return launch_pp<T>(g, stream, pl, sd);
     return launch_pipe<T, 128, 128, 64, 2, 2, 4>(g, stream);       // 8 waves, 64 x 32 wave tiles, 2 workgroups / CU
 }
 

@@ -26,6 +26,17 @@ struct GemmGroup {                        // passed by value as the kernel argum
     int32_t  interleave;                              // 1: every XCD gets a chunk of each problem (unequal K loops)
 };
 
+// Side problems of a ping-pong launch: the few short problems of a group whose K loop differs from the main ones (the
+// K = 2048 text-context projections next to the K = 1280 query projection of a cross-attention layer).  They run as
+// 128 x 128 lock-step tiles in the FIRST blocks of the same launch, so the main problems keep the big-tile engine.
+struct GemmSide {
+    GemmDesc p[4];
+    int32_t  tile_start[5];               // prefix sums of 128 x 128 tile counts
+    int32_t  n;                           // number of side problems (0 = none)
+    int32_t  tiles;                       // total side tiles
+    int32_t  pad_tiles;                   // tiles rounded up to a multiple of 8 (keeps block -> XCD of the main tiles)
+};
+
 // picks the tile shape, fills g.tile_start and launches
 hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const char** variant = nullptr);
 

@@ -766,3 +766,41 @@ def test_ip_processors_n_frame_generalisation(dtype, n, r):
                   O.ip_adapter_attention(rd["x"], rd["text"], rd["ip"], w, ipw)) < TOL[dtype]
     with pytest.raises(RuntimeError, match="frames"):
         aid_amd.OuterInterpolatedIPAttnProcessor(size=n + 1, is_fused=True, ip_attn=ipa)(attn, x, encoder_hidden_states=ehs)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+def test_gemm_side_problems_ride_in_the_pingpong_launch(dtype):
+    """Cross-attention projection group at SDXL size: the query projection (K = 1280) keeps the 256 x 256 ping-pong engine,
+    the short text-context (and IP-Adapter image) projections with K = 2048 run as 128 x 128 side tiles of the same launch.
+    Every output against fp64 on sampled rows."""
+    n, s, c, cc, l, nctx, t_ip = 14, 1024, 1280, 2048, 77, 6, 4
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(n * s, c, generator=g).to(dtype)
+    e = torch.randn(nctx, l, cc, generator=g).to(dtype)
+    ip = torch.randn(nctx, t_ip, cc, generator=g).to(dtype)
+    wq, wk, wv, wki, wvi = ((torch.randn(c, kk, generator=g) / kk ** 0.5).to(dtype) for kk in (c, cc, cc, cc, cc))
+    d = lambda t: t.to(DEV)     # noqa: E731
+    xd, ed, ipd, wqd, wkd, wvd, wkid, wvid = map(d, (x, e, ip, wq, wk, wv, wki, wvi))
+    q = torch.empty(n * s, c, dtype=dtype, device=DEV)
+    k = torch.empty(nctx, l, c, dtype=dtype, device=DEV)
+    vt = torch.zeros(nctx, c, 80, dtype=dtype, device=DEV)
+    kip = torch.empty(nctx, t_ip, c, dtype=dtype, device=DEV)
+    vtip = torch.zeros(nctx, c, 8, dtype=dtype, device=DEV)
+    probs = [dict(a=xd, b=wqd, c=q, m=n * s, n=c, k=c, lda=c, ldb=c, ldc=c),
+             dict(a=ed, b=wkd, c=k, m=nctx * l, n=c, k=cc, lda=cc, ldb=cc, ldc=c),
+             dict(a=wvd, b=ed, c=vt, m=c, n=l, k=cc, lda=cc, ldb=cc, ldc=80, batch=nctx, stride_a=0, stride_b=l * cc, stride_c=c * 80),
+             dict(a=ipd, b=wkid, c=kip, m=t_ip, n=c, k=cc, lda=cc, ldb=cc, ldc=c, batch=nctx, stride_a=t_ip * cc, stride_b=0,
+                  stride_c=t_ip * c),
+             dict(a=wvid, b=ipd, c=vtip, m=c, n=t_ip, k=cc, lda=cc, ldb=cc, ldc=8, batch=nctx, stride_a=0, stride_b=t_ip * cc,
+                  stride_c=c * 8)]
+    for group in (probs[:3], probs):
+        ops.gemm_nt(group)
+        assert ops.last_gemm_variant().startswith("pingpong256") and ops.last_gemm_variant().endswith("side128"), \
+            ops.last_gemm_variant()
+        rows = torch.tensor([0, 127, 128, 255, 256, 5000, n * s - 1])
+        assert rel_l2(to_np64(q[rows]), to_np64(x[rows]) @ to_np64(wq).T) < TOL_GEMM[dtype]
+        assert rel_l2(to_np64(k), to_np64(e) @ to_np64(wk).T) < TOL_GEMM[dtype]
+        ref_vt = np.einsum("ck,flk->fcl", to_np64(wv), to_np64(e))
+        assert rel_l2(to_np64(vt[:, :, :l]), ref_vt) < TOL_GEMM[dtype] and float(vt[:, :, l:].abs().max()) == 0.0
+    assert rel_l2(to_np64(kip), to_np64(ip) @ to_np64(wki).T) < TOL_GEMM[dtype]
+    assert rel_l2(to_np64(vtip[:, :, :t_ip]), np.einsum("ck,ftk->fct", to_np64(wvi), to_np64(ip))) < TOL_GEMM[dtype]
