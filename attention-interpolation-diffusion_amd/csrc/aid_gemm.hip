@@ -598,6 +598,12 @@ struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
     }
 };
 
+// The 128 x 128 tiles inside a ping-pong launch (side problems, ragged last round) have the CU to themselves — the launch
+// reserves the big tile's 128 KB of LDS per workgroup — so their DMA ring is 4 deep instead of the lock-step kernel's 2:
+// a lone workgroup has nobody to hide the L2 round trip of the next K tile behind.
+constexpr int PP_SMALL_NS = 4;
+static_assert(Engine<bf16, 128, 128, 64, PP_SMALL_NS, 2, 4>::SMEM <= PingPong<bf16>::SMEM, "small tiles use the big tile's LDS");
+
 template <typename T>
 __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, const int n_big, const GemmSide sd) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         const T* A = reinterpret_cast<const T*>(P.a) + (int64_t)batch * P.stride_a;
         const T* B = reinterpret_cast<const T*>(P.b) + (int64_t)batch * P.stride_b;
         T* C = reinterpret_cast<T*>(P.c) + (int64_t)batch * P.stride_c;
-        Engine<T, 128, 128, 64, 2, 2, 4> e;
+        Engine<T, 128, 128, 64, PP_SMALL_NS, 2, 4> e;
         e.init(smem_raw);
         e.set_tile(P, A, B, m0, n0);
         e.zero_acc();
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         const T* A = reinterpret_cast<const T*>(P.a) + (int64_t)tc.batch * P.stride_a;
         const T* B = reinterpret_cast<const T*>(P.b) + (int64_t)tc.batch * P.stride_b;
         T* C = reinterpret_cast<T*>(P.c) + (int64_t)tc.batch * P.stride_c;
-        Engine<T, 128, 128, 64, 2, 2, 4> e;
+        Engine<T, 128, 128, 64, PP_SMALL_NS, 2, 4> e;
         e.init(smem_raw);
         e.set_tile(P, A, B, tc.m0, tc.n0);
         e.zero_acc();
