@@ -62,7 +62,14 @@ struct AttnKParams {
     AidAttnArgs a;
     int32_t nqb;                        // q blocks per (frame, head)
     float   c2;                         // softmax_scale * log2(e)
+    int32_t q_iters;                    // resident variant: q blocks a workgroup works through one after the other
 };
+
+// Resident variant (short key sets: the 77 text tokens of cross-attention, IP-Adapter image tokens): every key segment of the
+// (frame, head) sits in LDS for the whole life of the workgroup — RES_KEYS key rows of K and V^T rows of RES_KEYS + 8 keys.
+constexpr int RES_KEYS = 96;
+constexpr int RES_VLD = RES_KEYS + 8;
+constexpr int RES_SLACK = 64;           // zeroed elements behind the last segment: the masked half of a ragged tile reads on
 
 __host__ __device__ constexpr bool attn_prefetch(int d, int nw) { return (nw == 4 || nw == 8) && d <= 80; }
 
@@ -97,7 +104,11 @@ __device__ __forceinline__ f32x16 zero16() {
 // VALU work of tile t in the gaps between them, order pinned by sched_barrier — one wave then overlaps its own matrix
 // and vector work instead of running QK | softmax | PV back to back (tools/ubench/overlap.hip: 0.404 -> 0.341 us per
 // wave-tile in the register-only model at 3 waves / SIMD, 0.560 -> 0.419 at one).
-template <typename T, int D, int MODE, int NW, int QB, bool PIPE>
+// RES = resident key segments (a.l <= RES_KEYS): the streaming kernel spends a 77-key launch waiting — three segments of two
+// tiles, each a global -> register -> LDS round trip behind a barrier, for 128 query rows.  Here a workgroup loads the one to
+// three segments of its (frame, head) ONCE (zero-padded to RES_KEYS keys), then every wave runs q block after q block out of
+// LDS with no barrier at all; two workgroups per CU overlap one's fill with the other's arithmetic.
+template <typename T, int D, int MODE, int NW, int QB, bool PIPE, bool RES>
 __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) {
     typedef typename Vec<T>::v8 T8;
     typedef typename Vec<T>::v4 T4;
@@ -112,13 +123,17 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     constexpr int NVC = (VCH + NT - 1) / NT;    // Vt chunks per thread per tile
     // Prefetch (issue tile t+1's loads before tile t's compute, two LDS buffers) only where the staging
     // registers fit beside the accumulators; otherwise stage synchronously through one buffer.
-    constexpr bool PREFETCH = attn_prefetch(D, NW) || QB > 1;
+    constexpr bool PREFETCH = !RES && (attn_prefetch(D, NW) || QB > 1);
     constexpr int NBUF = PREFETCH ? 2 : 1;
+    constexpr int VROW = RES ? RES_VLD : VLD;                   // V^T row stride in LDS (elements)
+    constexpr int RSEG = RES_KEYS * KLD + DV * RES_VLD;         // elements of one resident segment: K rows, then V^T rows
+    static_assert(!RES || (QB == 1 && !PIPE), "resident variant: one q block per wave, program-order tile");
+    static_assert((RES_VLD / 8) % 2 == 1 && RSEG % 8 == 0, "resident rows: odd number of 16-B slots");
     // row of ones in V^T -> the row sums l come out of the second MFMA as a row of O^T.  A spare padded row
     // (index D) exists for d = 40 / 80; d = 64 / 160 use one eXtra 32-row block fed from a constant fragment.
     constexpr bool XL = (D == DV);
     constexpr bool KPIPE = true;                // K fragment reads two k-steps ahead of their MFMAs (see tile())
-    constexpr bool PERSIST_C = QB > 1 || (D <= 64 && !(KPIPE && D == 64 && MODE == AID_MODE_PLAIN));   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
+    constexpr bool PERSIST_C = !RES && (QB > 1 || (D <= 64 && !(KPIPE && D == 64 && MODE == AID_MODE_PLAIN)));   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
     constexpr int LBLK = D / 32, LREG = ((D % 32) / 8) * 4;     // (block, register) of row D at lanes hi == 0
     static_assert(XL || ((D % 32) % 8 == 0 && (D % 32) < 32), "spare row must sit at a register boundary");
     // head-room (log2) of P = 2^x in the storage type before the row reference has to be raised
@@ -144,21 +159,22 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const int qb = lid % p.nqb;
     const int fr = (lid / p.nqb) % a.n_frames;
     const int h = lid / (p.nqb * a.n_frames);
-    const int q0 = (qb * NW + wave) * 32 * QB;
+    int q0 = (qb * (RES ? p.q_iters : 1) * NW + wave) * 32 * QB;
 
     // zero both LDS buffers once where the head dim is padded (d = 40 / 80): pad columns of K / pad rows of V^T are
     // never staged and must be finite.  d = 64 / 160 have no padding that a fragment read touches.
-    if (DK != D || DV != D) {
+    if (!RES && (DK != D || DV != D)) {
         for (int i = tid; i < NBUF * (KT * KLD + DV * VLD) / 8; i += NT)
             reinterpret_cast<T8*>(Ks)[i] = zero8<T>();
     }
-    if (!XL) {                                          // the ones row (never touched by the staging, which writes rows < D)
+    if (!RES && !XL) {                                  // the ones row (never touched by the staging, which writes rows < D)
         __syncthreads();
         for (int i = tid; i < NBUF * KT; i += NT) Vs[(i / KT) * DV * VLD + D * VLD + (i % KT)] = (T)1.0f;
     }
 
     // ---- Q fragments (B operand of the swapped product), straight from global -------------
     T8 qf[QB][NQK];
+    auto load_q = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         const int qr = min(q0 + 32 * j + l31, a.s - 1);  // rows past the end are clamped, never stored
@@ -175,6 +191,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             }
         }
     }
+    };
+    if (!RES) load_q();
     // constant A fragment of the row-sum block (XL): row 0 = ones, every other row zero
     T8 onesf;
 #pragma unroll
@@ -205,7 +223,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 
     // ---- one segment of keys: online-softmax update of `st` ----------------------------------
     // k0/v0: frame base pointers (already offset to head h)
-    auto run = [&](OState<NDB, XL, QB>& st, const T* k0, const T* v0) __attribute__((always_inline)) {
+    // k0/v0: frame base pointers (already offset to head h); reg: LDS region of the segment (resident variant)
+    auto run = [&](OState<NDB, XL, QB>& st, const T* k0, const T* v0, int reg) __attribute__((always_inline)) {
         T8 rk[PREFETCH ? NKC : 1], rv[PREFETCH ? NVC : 1];
         // buffer descriptors of the segment's K / Vt (wave-uniform); per-lane byte offsets are 32-bit and the
         // tile advance goes into the scalar offset, so a full tile costs no address VALU at all
@@ -307,9 +326,13 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         };
 
         // ---- compute on one staged tile; FULL = all 64 keys valid ---------------------------------
-        auto tile = [&](int buf, int key0, auto full_tag) __attribute__((always_inline)) {
+        auto tile = [&](const T* ksrc, const T* vsrc, int key0, auto full_tag) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
-            const int nb = FULL ? 2 : ((L - key0 > 32) ? 2 : 1);   // 32-key blocks with any valid key
+            // A ragged tile runs the SAME straight-line MFMA sequence as a full one and masks afterwards: keys past L
+            // have finite K rows / zero V^T columns in LDS.  (Skipping the second 32-key block with a branch saved four
+            // MFMAs and cost correctness: on the taken path hipcc left too few wait states between the last MFMA of
+            // block 0 and the first VALU read of its result — the score of keys 22 / 30 of the tile lacked its last
+            // k-step whenever 16 < L % 64 <= 32.)
             // x^T = K Q'^T - m : the accumulator starts at -m, so the MFMA result is the exponent argument
             // (kept in registers across tiles where the budget allows: re-broadcasting it costs 16 v_mov per tile, a
             // sixth of the VALU instructions of a kernel that is VALU-issue bound — profiles/r01_attn_notes.txt)
@@ -324,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 }
             }
             f32x16 sc[QB][2];
-            const T* kt = Ks + buf * KT * KLD + krow * KLD + hi * 8;
+            const T* kt = ksrc + krow * KLD + hi * 8;
             auto qk = [&](auto zero_tag) __attribute__((always_inline)) {
             constexpr bool ZERO = decltype(zero_tag)::value;
             // k-step outer, key-block inner: consecutive MFMAs go to DIFFERENT accumulators, so the dependent
@@ -361,8 +384,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 #pragma unroll
                     for (int j = 0; j < QB; ++j) {
                         sc[j][0] = mfma32(k0f, qf[j][ks], ks ? sc[j][0] : (ZERO ? zero16() : cneg[j]));
-                        if (FULL || nb > 1) sc[j][1] = mfma32(k1f, qf[j][ks], ks ? sc[j][1] : (ZERO ? zero16() : cneg[j]));
-                        else if (ks == 0)   sc[j][1] = ZERO ? zero16() : cneg[j];
+                        sc[j][1] = mfma32(k1f, qf[j][ks], ks ? sc[j][1] : (ZERO ? zero16() : cneg[j]));
                     }
                 }
             }
@@ -446,20 +468,18 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                         pf[j][2 * b + u] = cvt8<T>(pv);
                     }
             // O^T += Vt P^T   (the ones row / ones block accumulates the row sums); a V^T fragment read serves all QB blocks
-            const T* vt = Vs + buf * DV * VLD + l31 * VLD + hi * 8;
+            const T* vt = vsrc + l31 * VROW + hi * 8;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                if (FULL || kk < 2 * nb) {
 #pragma unroll
-                    for (int d = 0; d < NDB; ++d) {
-                        const T8 vf = *reinterpret_cast<const T8*>(vt + d * 32 * VLD + kk * 16);
+                for (int d = 0; d < NDB; ++d) {
+                    const T8 vf = *reinterpret_cast<const T8*>(vt + d * 32 * VROW + kk * 16);
 #pragma unroll
-                        for (int j = 0; j < QB; ++j) st.o[j][d] = mfma32(vf, pf[j][kk], st.o[j][d]);
-                    }
-                    if (XL) {
+                    for (int j = 0; j < QB; ++j) st.o[j][d] = mfma32(vf, pf[j][kk], st.o[j][d]);
+                }
+                if (XL) {
 #pragma unroll
-                        for (int j = 0; j < QB; ++j) st.ol[j] = mfma32(onesf, pf[j][kk], st.ol[j]);
-                    }
+                    for (int j = 0; j < QB; ++j) st.ol[j] = mfma32(onesf, pf[j][kk], st.ol[j]);
                 }
             }
         };
@@ -755,6 +775,13 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         const int nt = (L + KT - 1) / KT;
         const int nfull = L / KT;
         int t = 0;
+        if (RES) {                                      // at most one full and one ragged tile, both already in LDS
+            const T* kb = Ks + reg * RSEG;
+            const T* vb = kb + RES_KEYS * KLD;
+            if (nfull) tile(kb, vb, 0, std::true_type{});
+            if (nt > nfull) tile(kb + nfull * KT * KLD, vb + nfull * KT, nfull * KT, std::false_type{});
+            return;
+        }
         if (PIPE && nfull >= 3) {                       // pipelined over an odd number of full tiles, the rest below
             const int nfp = (nfull & 1) ? nfull : nfull - 1;
             run_pipe(nfp);
@@ -777,7 +804,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 stage_sync(key0);
                 __syncthreads();
             }
-            tile(buf, key0, std::true_type{});
+            tile(Ks + buf * KT * KLD, Vs + buf * DV * VLD, key0, std::true_type{});
             if (PREFETCH) {
                 if (t + 1 < nfull)   stage_write(buf ^ 1, key0 + KT, std::true_type{});
                 else if (t + 1 < nt) stage_write(buf ^ 1, key0 + KT, std::false_type{});
@@ -790,7 +817,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 stage_sync(key0);
                 __syncthreads();
             }
-            tile(buf, key0, std::false_type{});
+            tile(Ks + buf * KT * KLD, Vs + buf * DV * VLD, key0, std::false_type{});
             __syncthreads();
         }
     };
@@ -835,43 +862,95 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const T* k_end = Kg + (int64_t)a.end * a.k_fs;
     const T* v_end = Vg + (int64_t)a.end * a.vt_fs;
 
+    // Which segments this frame runs (the same decisions for every q block of the workgroup):
+    //  single — (1) PLAIN; (2) negative coefficient = this frame is PLAIN inside an INNER / OUTER launch (the unconditional
+    //           half of a classifier-free-guidance batch rides in the same call); (3) a fused END-POINT frame: its second
+    //           segment would be its own keys again ([K_0 ; K_0]) — duplicating every key leaves softmax(QK^T)V unchanged
+    //           (SURVEY.md §4 invariant), so one pass over the own keys is the same result with half the work.
+    //  INNER  — coefficient exactly 0 / 1: the lerp is the end-point frame itself; interior frames read the interpolated
+    //           keys / values that aid_lerp_kv wrote to k2 / vt2.
+    const bool single = MODE == AID_MODE_PLAIN || cf < 0.f ||
+                        (a.fused && ((cf == 0.f && kvf == a.begin) || (cf == 1.f && kvf == a.end)));
+    const bool own_first = single || a.fused;
+    const T* k_mix = k_beg;
+    const T* v_mix = v_beg;
+    if (MODE == AID_MODE_INNER) {
+        if (cf == 1.f) { k_mix = k_end; v_mix = v_end; }
+        else if (cf != 0.f) {
+            k_mix = reinterpret_cast<const T*>(a.k2) + h * D + (int64_t)fr * a.k_fs;
+            v_mix = reinterpret_cast<const T*>(a.vt2) + (int64_t)(h * D) * a.ldvt + (int64_t)fr * a.vt_fs;
+        }
+    }
+    const int r_own = 0, r_mix = own_first ? 1 : 0;             // LDS regions (resident variant)
+    const int r_beg = r_mix, r_end = r_mix + (cf != 1.f ? 1 : 0);
+
+    if (RES) {
+        // ---- fill: every segment this frame needs, once per workgroup -------------------------------------------
+        T* const L0 = reinterpret_cast<T*>(smem_raw);
+        constexpr int NREG = MODE == AID_MODE_PLAIN ? 1 : MODE == AID_MODE_INNER ? 2 : 3;
+        for (int i = tid; i < (NREG * RSEG + RES_SLACK) / 8; i += NT) reinterpret_cast<T8*>(L0)[i] = zero8<T>();
+        __syncthreads();
+        auto fill = [&](int reg, const T* k0, const T* v0) __attribute__((always_inline)) {
+            T* kb = L0 + reg * RSEG;
+            T* vb = kb + RES_KEYS * KLD;
+            for (int id = tid; id < L * DC; id += NT) {
+                const int row = id / DC, c = id % DC;
+                *reinterpret_cast<T8*>(kb + row * KLD + c * 8) = *reinterpret_cast<const T8*>(k0 + (int64_t)row * a.ldk + c * 8);
+            }
+            const int nch = (L + 7) >> 3;
+            for (int id = tid; id < D * nch; id += NT) {
+                const int row = id / nch, kc = (id % nch) * 8;
+                T8 v = *reinterpret_cast<const T8*>(v0 + (int64_t)row * a.ldvt + kc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (kc + e >= L) v[e] = (T)0.0f;            // keys >= L get P = 0; their V must be finite
+                *reinterpret_cast<T8*>(vb + row * RES_VLD + kc) = v;
+            }
+            if (!XL)
+                for (int i = tid; i < RES_KEYS; i += NT) vb[D * RES_VLD + i] = (T)1.0f;     // the ones row
+        };
+        if (own_first) fill(r_own, k_own, v_own);
+        if (!single) {
+            if (MODE == AID_MODE_INNER) {
+                fill(r_mix, k_mix, v_mix);
+            } else {
+                if (cf != 1.f) fill(r_beg, k_beg, v_beg);
+                if (cf != 0.f) fill(r_end, k_end, v_end);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int n_it = RES ? p.q_iters : 1;
+    for (int it = 0; it < n_it; ++it, q0 += NW * 32 * QB) {
+    if (RES) {
+        if (q0 >= a.s) break;                           // no barrier below: a wave may leave on its own
+        load_q();
+    }
     State st;
     init(st);
     f32x16 res[QB][NDB];
 
-    if (MODE == AID_MODE_PLAIN) {
-        run(st, k_own, v_own);
-        finish(res, st, 1.f, false);
-    } else if (cf < 0.f || (a.fused && ((cf == 0.f && kvf == a.begin) || (cf == 1.f && kvf == a.end)))) {
-        // (1) negative coefficient = this frame is PLAIN inside an INNER / OUTER launch (the unconditional half of
-        //     a classifier-free-guidance batch rides in the same call);
-        // (2) a fused END-POINT frame: its second segment would be its own keys again ([K_0 ; K_0]) — duplicating
-        //     every key leaves softmax(QK^T)V unchanged (SURVEY.md §4 invariant), so one pass over the own keys is
-        //     the same result with half the work.
-        run(st, k_own, v_own);
+    if (single) {
+        run(st, k_own, v_own, r_own);
         finish(res, st, 1.f, false);
     } else if (MODE == AID_MODE_INNER) {
-        if (a.fused) run(st, k_own, v_own);
-        // coefficient exactly 0 / 1: the lerp is the end-point frame itself; interior frames read the
-        // interpolated keys / values that aid_lerp_kv wrote to k2 / vt2
-        if (cf == 0.f)      run(st, k_beg, v_beg);
-        else if (cf == 1.f) run(st, k_end, v_end);
-        else                run(st, reinterpret_cast<const T*>(a.k2) + h * D + (int64_t)fr * a.k_fs,
-                                reinterpret_cast<const T*>(a.vt2) + (int64_t)(h * D) * a.ldvt + (int64_t)fr * a.vt_fs);
+        if (a.fused) run(st, k_own, v_own, r_own);
+        run(st, k_mix, v_mix, r_mix);
         finish(res, st, 1.f, false);
     } else {
-        if (a.fused) run(st, k_own, v_own);
+        if (a.fused) run(st, k_own, v_own, r_own);
 #pragma unroll
         for (int j = 0; j < QB; ++j)
 #pragma unroll
             for (int d = 0; d < NDB; ++d) res[j][d] = zero16();
         if (cf != 1.f) {                                    // begin side, weight (1 - c)
             State sb = st;
-            run(sb, k_beg, v_beg);
+            run(sb, k_beg, v_beg, r_beg);
             finish(res, sb, 1.f - cf, false);
         }
         if (cf != 0.f) {                                    // end side, weight c
-            run(st, k_end, v_end);
+            run(st, k_end, v_end, r_end);
             finish(res, st, cf, true);
         }
     }
@@ -901,24 +980,27 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 }
         }
     }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D, int MODE, int NW, int QB, bool PIPE>
+template <typename T, int D, int MODE, int NW, int QB, bool PIPE, bool RES = false>
 static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
-    const size_t smem = (size_t)((attn_prefetch(D, NW) || QB > 1) ? 2 : 1) * (KT * (DK + 8) + DV * VLD) * sizeof(T);
+    constexpr int NREG = MODE == AID_MODE_PLAIN ? 1 : MODE == AID_MODE_INNER ? 2 : 3;
+    const size_t smem = RES ? ((size_t)NREG * (RES_KEYS * (DK + 8) + DV * RES_VLD) + RES_SLACK) * sizeof(T)
+                            : (size_t)((attn_prefetch(D, NW) || QB > 1) ? 2 : 1) * (KT * (DK + 8) + DV * VLD) * sizeof(T);
     static PerDevice<bool> attr_set;
     bool* done = attr_set.slot();
     if (!done) return hipErrorInvalidDevice;
     if (!*done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW, QB, PIPE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW, QB, PIPE, RES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         *done = true;
     }
     const int grid = p.nqb * p.a.n_frames * p.a.heads;
-    hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW, QB, PIPE>), dim3(grid), dim3(NW * 64), smem, stream, p);
+    hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW, QB, PIPE, RES>), dim3(grid), dim3(NW * 64), smem, stream, p);
     return hipGetLastError();
 }
 
@@ -961,8 +1043,26 @@ static bool attn_pipe(const AidAttnArgs& a) {
     return a.d == 40 && a.mode == AID_MODE_INNER;
 }
 
+// Resident key segments: short key sets (text tokens, image tokens) at d <= 80.  A workgroup (4 waves) takes 1 / RES_CHUNKS
+// of the query rows of its (frame, head): fewer chunks amortise the fill better, more chunks give the dispatcher something to
+// balance the one- and three-segment frames of a batched-CFG launch with.  Development knob AID_ATTN_RES = 0 / 1.
+constexpr int RES_CHUNKS = 4;
+static bool attn_res(const AidAttnArgs& a) {
+    const char* env = getenv("AID_ATTN_RES");
+    if (a.d > 80 || a.l > RES_KEYS) return false;
+    if (env) return atoi(env) != 0;
+    return true;
+}
+
 template <typename T, int D, int MODE>
 static hipError_t launch_nw(AttnKParams& p, hipStream_t stream) {
+    p.q_iters = 1;
+    if (D <= 80 && attn_res(p.a)) {
+        const int nqb = (p.a.s + 127) / 128;                    // 128-row blocks (4 waves x 32 rows)
+        p.nqb = nqb < RES_CHUNKS ? nqb : RES_CHUNKS;
+        p.q_iters = (nqb + p.nqb - 1) / p.nqb;
+        return launch_variant<T, D, MODE, 4, 1, false, (D <= 80)>(p, stream);
+    }
     if (D == 40 && MODE == AID_MODE_PLAIN && attn_qb(p.a) == 2) {
         p.nqb = (p.a.s + 255) / 256;
         return launch_variant<T, D, MODE, 4, (D == 40 && MODE == AID_MODE_PLAIN) ? 2 : 1, false>(p, stream);
@@ -1046,7 +1146,9 @@ bool attn_head_dim_supported(int d) { return d == 40 || d == 64 || d == 80 || d 
 const char* attn_variant_name(const AidAttnArgs& a) {
     static thread_local char name[64];
     static const char* modes[] = {"plain", "inner", "outer"};
-    if (attn_qb(a) == 2)
+    if (attn_res(a))
+        snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,res>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d, modes[a.mode]);
+    else if (attn_qb(a) == 2)
         snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d,qb2>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,
                  modes[a.mode], attn_nw(a));
     else if (attn_nw(a) != 8 && attn_pipe(a))
@@ -1062,6 +1164,7 @@ hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** va
     AttnKParams p;
     p.a = a;
     p.nqb = 0;
+    p.q_iters = 1;
     p.c2 = a.softmax_scale * 1.4426950408889634f;
     hipError_t e = (a.dtype == AID_DTYPE_F16) ? launch_d<f16>(p, stream) : launch_d<bf16>(p, stream);
     if (variant) *variant = attn_variant_name(a);

@@ -165,6 +165,28 @@ def test_attention_core_all_modes(dtype, d, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("d", [40, 64, 80])
+@pytest.mark.parametrize("resident", ["0", "1"], ids=["streaming", "resident"])
+def test_attention_every_ragged_key_count(dtype, d, resident, monkeypatch):
+    """Every number of valid keys in the last (ragged) tile, on the streaming kernel and on the resident-segment
+    kernel (which serves l <= 96 by default).  16 < l % 64 <= 32 is the case a branchy ragged tile got wrong on the
+    resident kernel: hipcc left too few wait states between the last MFMA of a score block and the first VALU read of it
+    on the taken path (keys 22 / 30 of the tile lost their last k-step) — the tile is straight-line now."""
+    monkeypatch.setenv("AID_ATTN_RES", resident)           # the library reads the knob per call
+    n, s, h = 3, 48, 2
+    coef = _coef(n)
+    for l in (1, 7, 8, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 77, 80, 88, 95, 96, 97, 120, 128, 160):
+        q, k, v, vt = _core_inputs(n, s, l, h, d, dtype, seed=l)
+        for mode, fused in MODES:
+            o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused, coef=coef.to(DEV))
+            name = ops.last_attn_variant()
+            assert ("res" in name) == (resident == "1" and l <= 96), (l, name)
+            ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, mode, fused, coef.numpy())
+            err = rel_l2(to_np64(o), ref)
+            assert err < TOL[dtype], (l, mode, fused, name, err)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
 def test_attention_core_sharded_endpoints_accumulate_and_maps(dtype):
     """begin/end != (0, N-1), kv_map, frame_scale, out_scale and accumulate (what the IP processors and
     the frame-sharded multi-GPU layout use)."""
