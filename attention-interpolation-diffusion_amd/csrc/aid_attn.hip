@@ -85,6 +85,28 @@ struct OState {
     f32x16 cn[QB];                      // -m in all 16 registers (C operand of the first MFMA), kept when PERSIST_C
 };
 
+// Block -> logical id for a launch that mixes interpolated frames (up to three key segments per q block) with PLAIN riders
+// (one segment): inside every XCD's contiguous range the heavy workgroups are listed FIRST, so a range never ends on a
+// late-started three-segment workgroup running alone (S = 1024 OUTER with 7 + 7 frames: a workgroup lives 10 - 40 us of a
+// 180 us launch).  `per` = workgroups per head, the first `na` of them heavy; a stable partition of the XCD's range, so
+// neighbours still share K / V^T in that XCD's L2.  Any (na, per) gives a bijection: a wrong hint only costs balance.
+__device__ __forceinline__ int heavy_first(int bid, int nblocks, int na, int per) {
+    constexpr int NX = 8;
+    const int q = nblocks / NX, r = nblocks % NX;
+    const int x = bid % NX, j = bid / NX;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    const int end = base + q + (x < r ? 1 : 0);
+    const int nb = per - na;
+    const int a0 = (base / per) * na + min(base % per, na);         // heavy ids below `base`
+    const int a1 = (end / per) * na + min(end % per, na);
+    if (j < a1 - a0) {
+        const int t = a0 + j;
+        return (t / na) * per + t % na;
+    }
+    const int t = (base - a0) + (j - (a1 - a0));                     // light ids below `base`, plus the position among the lights
+    return (t / nb) * per + na + t % nb;
+}
+
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 __device__ __forceinline__ Rsrc make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
@@ -155,7 +177,10 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_heavy = a.n_frames - a.n_plain;                 // riders sit at the tail of the batch (hint, see heavy_first)
+    const int lid = (MODE != AID_MODE_PLAIN && a.n_plain > 0 && n_heavy > 0)
+                        ? heavy_first(blockIdx.x, gridDim.x, n_heavy * p.nqb, a.n_frames * p.nqb)
+                        : xcd_remap(blockIdx.x, gridDim.x);
     const int qb = lid % p.nqb;
     const int fr = (lid / p.nqb) % a.n_frames;
     const int h = lid / (p.nqb * a.n_frames);
@@ -174,25 +199,25 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 
     // ---- Q fragments (B operand of the swapped product), straight from global -------------
     T8 qf[QB][NQK];
-    auto load_q = [&]() __attribute__((always_inline)) {
+    auto load_q = [&](T8 (&qd)[QB][NQK], int qbase) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
-        const int qr = min(q0 + 32 * j + l31, a.s - 1);  // rows past the end are clamped, never stored
+        const int qr = min(qbase + 32 * j + l31, a.s - 1);  // rows past the end are clamped, never stored
         const T* qrow = reinterpret_cast<const T*>(a.q) + (int64_t)fr * a.q_fs + (int64_t)qr * a.ldq + h * D;
 #pragma unroll
         for (int ks = 0; ks < NQK; ++ks) {
             const int col = ks * 16 + hi * 8;
-            qf[j][ks] = (col < D) ? *reinterpret_cast<const T8*>(qrow + col) : zero8<T>();
+            qd[j][ks] = (col < D) ? *reinterpret_cast<const T8*>(qrow + col) : zero8<T>();
             if (!a.q_prescaled) {                       // generic callers: fold softmax_scale*log2(e) into Q here (one
-                f32x8 t = up8<T>(qf[j][ks]);            // extra rounding; the processor path does it in the GEMM epilogue)
+                f32x8 t = up8<T>(qd[j][ks]);            // extra rounding; the processor path does it in the GEMM epilogue)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] *= p.c2;
-                qf[j][ks] = cvt8<T>(t);
+                qd[j][ks] = cvt8<T>(t);
             }
         }
     }
     };
-    if (!RES) load_q();
+    if (!RES || q0 < a.s) load_q(qf, q0);               // resident variant: the first q block's loads fly during the fill
     // constant A fragment of the row-sum block (XL): row 0 = ones, every other row zero
     T8 onesf;
 #pragma unroll
@@ -885,47 +910,71 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const int r_beg = r_mix, r_end = r_mix + (cf != 1.f ? 1 : 0);
 
     if (RES) {
-        // ---- fill: every segment this frame needs, once per workgroup -------------------------------------------
+        // ---- fill: every segment this frame needs, once per workgroup ------------------------------------------------
+        // One pass writes EVERY 16-B chunk of every region exactly once — key / value data, zeros (key rows and V^T
+        // columns past L, pad columns, unused regions: the masked half of a ragged tile reads them), the ones row —
+        // with all global loads of the pass in flight before the first LDS write, and one barrier.
         T* const L0 = reinterpret_cast<T*>(smem_raw);
         constexpr int NREG = MODE == AID_MODE_PLAIN ? 1 : MODE == AID_MODE_INNER ? 2 : 3;
-        for (int i = tid; i < (NREG * RSEG + RES_SLACK) / 8; i += NT) reinterpret_cast<T8*>(L0)[i] = zero8<T>();
-        __syncthreads();
-        auto fill = [&](int reg, const T* k0, const T* v0) __attribute__((always_inline)) {
-            T* kb = L0 + reg * RSEG;
-            T* vb = kb + RES_KEYS * KLD;
-            for (int id = tid; id < L * DC; id += NT) {
-                const int row = id / DC, c = id % DC;
-                *reinterpret_cast<T8*>(kb + row * KLD + c * 8) = *reinterpret_cast<const T8*>(k0 + (int64_t)row * a.ldk + c * 8);
-            }
-            const int nch = (L + 7) >> 3;
-            for (int id = tid; id < D * nch; id += NT) {
-                const int row = id / nch, kc = (id % nch) * 8;
-                T8 v = *reinterpret_cast<const T8*>(v0 + (int64_t)row * a.ldvt + kc);
+        constexpr int KC8 = KLD / 8, VC8 = RES_VLD / 8;             // chunks per K row / V^T row
+        constexpr int KCH8 = RES_KEYS * KC8, NCH = RSEG / 8;        // chunks of the K part / of a whole region
+        constexpr int NIT = (NCH + NT - 1) / NT;
+        const bool both = cf != 0.f && cf != 1.f;
+        const T* rk[3] = {own_first ? k_own : (MODE == AID_MODE_INNER ? k_mix : (cf != 1.f ? k_beg : k_end)),
+                          own_first ? (single ? nullptr : (MODE == AID_MODE_INNER ? k_mix : (cf != 1.f ? k_beg : k_end)))
+                                    : (MODE == AID_MODE_OUTER && both ? k_end : nullptr),
+                          (MODE == AID_MODE_OUTER && own_first && !single && both) ? k_end : nullptr};
+        const T* rv[3] = {own_first ? v_own : (MODE == AID_MODE_INNER ? v_mix : (cf != 1.f ? v_beg : v_end)),
+                          own_first ? (single ? nullptr : (MODE == AID_MODE_INNER ? v_mix : (cf != 1.f ? v_beg : v_end)))
+                                    : (MODE == AID_MODE_OUTER && both ? v_end : nullptr),
+                          (MODE == AID_MODE_OUTER && own_first && !single && both) ? v_end : nullptr};
+        const int nk8 = (L + 7) & ~7;
+        T8 one8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (kc + e >= L) v[e] = (T)0.0f;            // keys >= L get P = 0; their V must be finite
-                *reinterpret_cast<T8*>(vb + row * RES_VLD + kc) = v;
-            }
-            if (!XL)
-                for (int i = tid; i < RES_KEYS; i += NT) vb[D * RES_VLD + i] = (T)1.0f;     // the ones row
-        };
-        if (own_first) fill(r_own, k_own, v_own);
-        if (!single) {
-            if (MODE == AID_MODE_INNER) {
-                fill(r_mix, k_mix, v_mix);
-            } else {
-                if (cf != 1.f) fill(r_beg, k_beg, v_beg);
-                if (cf != 0.f) fill(r_end, k_end, v_end);
+        for (int e = 0; e < 8; ++e) one8[e] = (T)1.0f;
+        T8 stg[NREG][NIT];
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = tid + i * NT;
+                T8 v = zero8<T>();
+                if (idx < KCH8) {
+                    const int row = idx / KC8, c = idx % KC8;
+                    if (rk[r] != nullptr && row < L && c < DC)
+                        v = *reinterpret_cast<const T8*>(rk[r] + (int64_t)row * a.ldk + c * 8);
+                } else if (idx < NCH) {
+                    const int row = (idx - KCH8) / VC8, kc = ((idx - KCH8) % VC8) * 8;
+                    if (rv[r] != nullptr && row < D && kc < nk8) {
+                        v = *reinterpret_cast<const T8*>(rv[r] + (int64_t)row * a.ldvt + kc);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (kc + e >= L) v[e] = (T)0.0f;        // keys >= L get P = 0; their V must be finite
+                    } else if (!XL && row == D) {
+                        v = one8;                                   // the ones row: row sums out of the second product
+                    }
+                }
+                stg[r][i] = v;
             }
         }
+#pragma unroll
+        for (int r = 0; r < NREG; ++r)
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int idx = tid + i * NT;
+                if (idx < NCH) reinterpret_cast<T8*>(L0 + r * RSEG)[idx] = stg[r][i];
+            }
+        if (tid < RES_SLACK / 8) reinterpret_cast<T8*>(L0 + NREG * RSEG)[tid] = zero8<T>();
         __syncthreads();
     }
 
     const int n_it = RES ? p.q_iters : 1;
     for (int it = 0; it < n_it; ++it, q0 += NW * 32 * QB) {
+    T8 qn[QB][NQK];                                     // resident variant: next q block's fragments, loaded a block ahead
     if (RES) {
         if (q0 >= a.s) break;                           // no barrier below: a wave may leave on its own
-        load_q();
+        const int qnx = q0 + NW * 32 * QB;
+        if (it + 1 < n_it && qnx < a.s) load_q(qn, qnx);
     }
     State st;
     init(st);
@@ -979,6 +1028,12 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     }
                 }
         }
+    }
+    if (RES) {
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+#pragma unroll
+            for (int ks = 0; ks < NQK; ++ks) qf[j][ks] = qn[j][ks];
     }
     }
 }
@@ -1043,10 +1098,12 @@ static bool attn_pipe(const AidAttnArgs& a) {
     return a.d == 40 && a.mode == AID_MODE_INNER;
 }
 
-// Resident key segments: short key sets (text tokens, image tokens) at d <= 80.  A workgroup (4 waves) takes 1 / RES_CHUNKS
-// of the query rows of its (frame, head): fewer chunks amortise the fill better, more chunks give the dispatcher something to
-// balance the one- and three-segment frames of a batched-CFG launch with.  Development knob AID_ATTN_RES = 0 / 1.
-constexpr int RES_CHUNKS = 4;
+// Resident key segments: short key sets (text tokens, image tokens) at d <= 80.  A workgroup (4 waves) takes one chunk of the
+// query rows of its (frame, head) and works through it 128 rows at a time.  These launches are latency chains (start-up ->
+// fill -> per q block: scores, softmax, PV, store; 8 % of the MFMA rate), so the number of chunks trades start-up cost per row
+// against workgroups in flight: measured best at 4 chunks for S = 1024 and 8 for S = 4096 (1 or 2 chunks: +30 - 130 %,
+// one q block per workgroup: +20 %; profiles/r02_attn_notes.txt).  Development knobs AID_ATTN_RES = 0 / 1, AID_ATTN_RES_CHUNKS.
+constexpr int RES_CHUNKS_MAX = 8;
 static bool attn_res(const AidAttnArgs& a) {
     const char* env = getenv("AID_ATTN_RES");
     if (a.d > 80 || a.l > RES_KEYS) return false;
@@ -1059,7 +1116,9 @@ static hipError_t launch_nw(AttnKParams& p, hipStream_t stream) {
     p.q_iters = 1;
     if (D <= 80 && attn_res(p.a)) {
         const int nqb = (p.a.s + 127) / 128;                    // 128-row blocks (4 waves x 32 rows)
-        p.nqb = nqb < RES_CHUNKS ? nqb : RES_CHUNKS;
+        int chunks = nqb / 2 < 1 ? 1 : nqb / 2 > RES_CHUNKS_MAX ? RES_CHUNKS_MAX : nqb / 2;
+        if (const char* env = getenv("AID_ATTN_RES_CHUNKS")) chunks = atoi(env) > 0 ? atoi(env) : chunks;
+        p.nqb = nqb < chunks ? nqb : chunks;
         p.q_iters = (nqb + p.nqb - 1) / p.nqb;
         return launch_variant<T, D, MODE, 4, 1, false, (D <= 80)>(p, stream);
     }
@@ -1165,6 +1224,8 @@ hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** va
     p.a = a;
     p.nqb = 0;
     p.q_iters = 1;
+    if (const char* env = getenv("AID_ATTN_ORDER"))          // development knob: 0 = plain XCD order for mixed launches
+        if (atoi(env) == 0) p.a.n_plain = 0;
     p.c2 = a.softmax_scale * 1.4426950408889634f;
     hipError_t e = (a.dtype == AID_DTYPE_F16) ? launch_d<f16>(p, stream) : launch_d<bf16>(p, stream);
     if (variant) *variant = attn_variant_name(a);
