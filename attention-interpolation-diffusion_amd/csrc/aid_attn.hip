@@ -155,7 +155,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     // (index D) exists for d = 40 / 80; d = 64 / 160 use one eXtra 32-row block fed from a constant fragment.
     constexpr bool XL = (D == DV);
     constexpr bool KPIPE = true;                // K fragment reads two k-steps ahead of their MFMAs (see tile())
-    constexpr bool PERSIST_C = !RES && (QB > 1 || (D <= 64 && !(KPIPE && D == 64 && MODE == AID_MODE_PLAIN)));   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
+    constexpr bool PERSIST_C = !RES && (QB > 1 || (D <= 64 && !(KPIPE && D == 64 && MODE == AID_MODE_PLAIN) &&
+                                                   !(MODE == AID_MODE_OUTER && NW == 4)));   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
     constexpr int LBLK = D / 32, LREG = ((D % 32) / 8) * 4;     // (block, register) of row D at lanes hi == 0
     static_assert(XL || ((D % 32) % 8 == 0 && (D % 32) < 32), "spare row must sit at a register boundary");
     // head-room (log2) of P = 2^x in the storage type before the row reference has to be raised
@@ -1064,15 +1065,16 @@ static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
 static int attn_qb(const AidAttnArgs& a);
 
 // Waves per workgroup.  Eight waves (256 query rows sharing one K / V^T staging pass and barrier) pay only where the
-// kernel runs two waves per SIMD anyway: d = 64 OUTER (256 VGPRs) +4 % at S = 1024, +1 % at S = 4096; the three-wave PLAIN
-// kernels lose 5 - 19 % and the 77-key cross-attention launches 4 - 8 % (profiles/r02_attn_notes.txt).  Built for d <= 80;
-// development knob AID_ATTN_NW = 4 / 8.
+// kernel runs two waves per SIMD anyway: d = 64 OUTER at S = 4096 (+2 %; at S = 1024 the four-wave kernel — 221 VGPRs since
+// it stopped keeping the -m blocks of its two states in registers — is 4 % faster); the three-wave PLAIN kernels lose
+// 5 - 19 % and the 77-key cross-attention launches 4 - 8 % (profiles/r02_attn_notes.txt).  Built for d <= 80; development
+// knob AID_ATTN_NW = 4 / 8.
 static int attn_nw(const AidAttnArgs& a) {
     const char* env = getenv("AID_ATTN_NW");
     if (a.d > 80) return 4;
     if (attn_qb(a) >= 2) return 4;
     if (env) return atoi(env) == 8 ? 8 : 4;
-    return (a.d == 64 && a.mode == AID_MODE_OUTER && a.l >= 256) ? 8 : 4;
+    return (a.d == 64 && a.mode == AID_MODE_OUTER && a.l >= 2048) ? 8 : 4;
 }
 
 // query blocks (of 32 rows) per wave.  Measured (profiles/r02_attn_notes.txt, tools/kbench_attn_ab.py): 64 rows per wave
@@ -1108,7 +1110,7 @@ static bool attn_res(const AidAttnArgs& a) {
     const char* env = getenv("AID_ATTN_RES");
     if (a.d > 80 || a.l > RES_KEYS) return false;
     if (env) return atoi(env) != 0;
-    return true;
+    return a.d == 40;           // measured in the stacks: d = 40 -25 % (inner) / -14 % (plain); d = 64 / 80 within +-5 % of streaming
 }
 
 template <typename T, int D, int MODE>

@@ -180,7 +180,7 @@ def test_attention_every_ragged_key_count(dtype, d, resident, monkeypatch):
         for mode, fused in MODES:
             o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused, coef=coef.to(DEV))
             name = ops.last_attn_variant()
-            assert ("res" in name) == (resident == "1" and l <= 96), (l, name)
+            assert ("res" in name) == (resident == "1" and l <= 96 and d <= 80), (l, name)
             ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, mode, fused, coef.numpy())
             err = rel_l2(to_np64(o), ref)
             assert err < TOL[dtype], (l, mode, fused, name, err)
