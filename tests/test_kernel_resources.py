@@ -1,0 +1,77 @@
+"""Register budgets of the built gfx950 kernels (CPU test: reads the tables the build leaves next to the objects).
+
+The launch heuristics in csrc/aid_attn.hip / aid_gemm.hip assume a number of waves per SIMD for every kernel variant
+(VGPRs <= 168 -> 3, <= 256 -> 2, anything that needs AGPR copies -> 1).  A refactor that moves a variant across one of
+those lines costs 20 - 40 % of its speed without failing any parity test — it happened in round 2 (OUTER d64 nw4:
+256 -> 256 + 32 AGPRs, S = 1024 launch 179 -> 227 us) and was only found by bisecting against an older library."""
+import os
+import re
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "attention-interpolation-diffusion_amd", "csrc")
+
+
+def _table(name):
+    path = os.path.join(CSRC, name + ".resources.txt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not there: build the library first (python -c 'import __graft_entry__ as g; g.build()')")
+    out = {}
+    for blk in open(path).read().split("Name: ")[1:]:
+        sym = blk.split()[0]
+        num = lambda key: int(re.search(re.escape(key) + r": (\d+)", blk).group(1))   # noqa: E731
+        out[sym] = dict(vgpr=num("VGPRs"), agpr=num("AGPRs"), scratch=num("ScratchSize [bytes/lane]"),
+                        occ=num("Occupancy [waves/SIMD]"), spill=num("VGPRs Spill"))      # SGPR "spills" go to VGPR lanes: free
+    return out
+
+
+def _attn(tab):
+    """(dtype, d, mode, nw, qb, pipe, res) -> resources"""
+    out = {}
+    for sym, r in tab.items():
+        m = re.search(r"aid_attn_kernelIDF16(b?)_?Li(\d+)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)", sym)
+        if m:
+            out[("bf16" if m.group(1) else "f16", int(m.group(2)), "pio"[int(m.group(3))], int(m.group(4)), int(m.group(5)),
+                 bool(int(m.group(6))), bool(int(m.group(7))))] = r
+    return out
+
+
+def test_no_kernel_spills_or_uses_scratch():
+    for obj in ("aid_attn", "aid_gemm", "aid_norm"):
+        for sym, r in _table(obj).items():
+            assert r["scratch"] == 0 and r["spill"] == 0, (obj, sym, r)
+
+
+def test_attention_variants_keep_the_waves_per_simd_the_launcher_assumes():
+    a = _attn(_table("aid_attn"))
+    assert len(a) >= 60
+    for dt in ("f16", "bf16"):
+        # the variants the two bench stacks launch (launch_nw / attn_nw / attn_qb / attn_pipe / attn_res in aid_attn.hip)
+        want = {
+            (dt, 64, "p", 4, 1, False, False): 3,      # SDXL PLAIN: three waves per SIMD
+            (dt, 64, "o", 8, 1, False, False): 2,      # SDXL OUTER, L >= 2048
+            (dt, 64, "o", 4, 1, False, False): 2,      # SDXL OUTER, S = 1024 and the 77-key launches
+            (dt, 40, "i", 4, 1, True, False): 2,       # SD1.5 INNER, pipelined loop
+            (dt, 40, "p", 4, 2, False, False): 2,      # SD1.5 PLAIN, 64 rows per wave
+            (dt, 40, "i", 4, 1, False, True): 3,       # SD1.5 77-key launches: resident segments
+            (dt, 40, "p", 4, 1, False, True): 3,
+            (dt, 80, "i", 4, 1, False, False): 2,
+            (dt, 80, "p", 4, 1, False, False): 2,
+            (dt, 160, "i", 4, 1, False, False): 2,
+            (dt, 160, "p", 4, 1, False, False): 2,
+        }
+        for key, occ in want.items():
+            assert key in a, key
+            assert a[key]["occ"] >= occ and (a[key]["agpr"] == 0 or occ == 1), (key, a[key])
+    # every built variant except the known one-wave ones (d160 OUTER, OUTER with the pipelined loop) gets two waves
+    one_wave = [k for k, r in a.items() if r["occ"] < 2]
+    assert all((k[1] == 160 and k[2] == "o") or (k[2] == "o" and k[5]) for k in one_wave), one_wave
+
+
+def test_gemm_engines_fit_their_workgroups_per_cu():
+    g = _table("aid_gemm")
+    for sym, r in g.items():
+        if "aid_gemm_nt_pp_kernel" in sym:
+            assert r["vgpr"] + r["agpr"] <= 256, (sym, r)         # 8 waves per CU = 2 per SIMD
+        if "aid_gemm_nt_pipe_kernel" in sym:
+            assert r["vgpr"] + r["agpr"] <= 128, (sym, r)         # 2 workgroups of 8 waves per CU = 4 per SIMD
