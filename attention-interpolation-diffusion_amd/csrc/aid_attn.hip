@@ -156,7 +156,8 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     constexpr bool XL = (D == DV);
     constexpr bool KPIPE = true;                // K fragment reads two k-steps ahead of their MFMAs (see tile())
     constexpr bool PERSIST_C = !RES && (QB > 1 || (D <= 64 && !(KPIPE && D == 64 && MODE == AID_MODE_PLAIN) &&
-                                                   !(MODE == AID_MODE_OUTER && NW == 4)));   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
+                                                   !(MODE == AID_MODE_OUTER && NW == 4) &&
+                                                   !(D == 40 && MODE == AID_MODE_INNER && NW == 4 && !PIPE)));   // +16 VGPRs (outer: +32); d64 plain would drop to 2 waves/SIMD
     constexpr int LBLK = D / 32, LREG = ((D % 32) / 8) * 4;     // (block, register) of row D at lanes hi == 0
     static_assert(XL || ((D % 32) % 8 == 0 && (D % 32) < 32), "spare row must sit at a register boundary");
     // head-room (log2) of P = 2^x in the storage type before the row reference has to be raised
@@ -1090,14 +1091,16 @@ static int attn_qb(const AidAttnArgs& a) {
 
 // software-pipelined main loop.  Built for d = 40 (every mode) and d = 64 PLAIN; measured (profiles/r02_attn_notes.txt):
 // +5 % for d = 40 INNER (two waves per SIMD either way), neutral for d = 64 PLAIN (206 VGPRs: two waves per SIMD instead of
-// three), slower wherever the extra live tile pushes the kernel to one wave per SIMD (OUTER).  Default: d = 40 INNER on
-// segments of at least three full tiles; development knob AID_ATTN_PIPE = 0 / 1 forces it for the built variants.
+// three), slower wherever the extra live tile pushes the kernel to one wave per SIMD (OUTER).  It was the default for d = 40
+// INNER until the program-order kernel of that variant got under 168 VGPRs (152: no persistent -m block, one `mix` segment
+// instead of three code copies): three waves per SIMD beat the pipelined two (577 vs 588 us at S = 4096).  Not a default
+// any more; development knob AID_ATTN_PIPE = 0 / 1 forces it for the built variants.
 static bool attn_pipe(const AidAttnArgs& a) {
     const char* env = getenv("AID_ATTN_PIPE");
     const bool built = a.d == 40 || (a.d == 64 && a.mode == AID_MODE_PLAIN);
     if (!built || a.l < 192) return false;
     if (env) return atoi(env) != 0;
-    return a.d == 40 && a.mode == AID_MODE_INNER;
+    return false;
 }
 
 // Resident key segments: short key sets (text tokens, image tokens) at d <= 80.  A workgroup (4 waves) takes one chunk of the

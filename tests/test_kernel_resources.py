@@ -51,7 +51,7 @@ def test_attention_variants_keep_the_waves_per_simd_the_launcher_assumes():
             (dt, 64, "p", 4, 1, False, False): 3,      # SDXL PLAIN: three waves per SIMD
             (dt, 64, "o", 8, 1, False, False): 2,      # SDXL OUTER, L >= 2048
             (dt, 64, "o", 4, 1, False, False): 2,      # SDXL OUTER, S = 1024 and the 77-key launches
-            (dt, 40, "i", 4, 1, True, False): 2,       # SD1.5 INNER, pipelined loop
+            (dt, 40, "i", 4, 1, False, False): 3,      # SD1.5 INNER: three waves per SIMD (the pipelined variant has two)
             (dt, 40, "p", 4, 2, False, False): 2,      # SD1.5 PLAIN, 64 rows per wave
             (dt, 40, "i", 4, 1, False, True): 3,       # SD1.5 77-key launches: resident segments
             (dt, 40, "p", 4, 1, False, True): 3,

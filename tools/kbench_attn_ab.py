@@ -27,6 +27,8 @@ SHAPES = {
              ("sdxl S1024 x77 d64", torch.bfloat16, 1024, 77, 20, 64, ["outer", "plain"]),
              ("sdxl S4096 x77 d64", torch.bfloat16, 4096, 77, 10, 64, ["outer", "plain"])],
     "sd15": [("sd15 S4096 d40 H8", torch.float16, 4096, 4096, 8, 40, ["inner", "plain"]),
+             ("sd15 S1024 d80 H8", torch.float16, 1024, 1024, 8, 80, ["inner", "plain"]),
+             ("sd15 S256 d160 H8", torch.float16, 256, 256, 8, 160, ["inner", "plain"]),
              ("sd15 S4096 x77 d40", torch.float16, 4096, 77, 8, 40, ["inner", "plain"]),
              ("sd15 S1024 x77 d80", torch.float16, 1024, 77, 8, 80, ["inner", "plain"])],
 }
