@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AID_LIB_PATH") or os.path.join(PKG_DIR, "libaid_hip.so")   # override: development A/B builds
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
-AID_ABI_VERSION = 3
+AID_ABI_VERSION = 4
 DTYPE_F16, DTYPE_BF16 = 0, 1
 MODE_PLAIN, MODE_INNER, MODE_OUTER = 0, 1, 2
 GEMM_MAX_PROBLEMS = 6
@@ -23,7 +23,7 @@ IP_NONE, IP_SAME, IP_PLAIN = 0, 1, 2
 
 # every symbol include/aid_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
-    "aid_gemm_nt", "aid_layernorm", "aid_attn_fwd", "aid_lerp_kv", "aid_processor_workspace_bytes", "aid_processor_fwd",
+    "aid_gemm_nt", "aid_layernorm", "aid_ln_stats", "aid_ln_fold", "aid_attn_fwd", "aid_lerp_kv", "aid_processor_workspace_bytes", "aid_processor_fwd",
     "aid_abi_version", "aid_strerror", "aid_last_attn_variant", "aid_last_gemm_variant", "aid_device_info",
     "aid_profile_begin", "aid_profile_end",
 )
@@ -37,6 +37,8 @@ class AidGemmProblem(C.Structure):
         ("batch", C.c_int32), ("scale", C.c_float),
         ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64),
         ("residual", C.c_void_p),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_shift", C.c_void_p),
+        ("ln_side", C.c_int32), ("reserved0", C.c_int32), ("stride_stats", C.c_int64),
     ]
 
 
@@ -72,6 +74,7 @@ class AidProcessorArgs(C.Structure):
         ("ip_frame_scale", C.c_void_p), ("ip_stride", C.c_int64),
         ("n_ip", C.c_int32), ("t_ip", C.c_int32), ("ip_mode", C.c_int32), ("ip_scale", C.c_float),
         ("ip_begin", C.c_int32), ("ip_end", C.c_int32), ("seg_executed", C.c_int32), ("reserved0", C.c_int32),
+        ("ln_wq", C.c_void_p), ("ln_wk", C.c_void_p), ("ln_wv", C.c_void_p), ("ln_const", C.c_void_p),
     ]
 
 
@@ -117,6 +120,11 @@ def load() -> C.CDLL:
     lib.aid_layernorm.restype = C.c_int
     lib.aid_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                   C.c_int32, C.c_void_p]
+    lib.aid_ln_stats.restype = C.c_int
+    lib.aid_ln_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
+    lib.aid_ln_fold.restype = C.c_int
+    lib.aid_ln_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_void_p]
     lib.aid_attn_fwd.restype = C.c_int
     lib.aid_attn_fwd.argtypes = [C.POINTER(AidAttnArgs), C.c_void_p]
     lib.aid_lerp_kv.restype = C.c_int

@@ -89,7 +89,8 @@ Carve carve(const AidProcessorArgs& a) {
         c.vt2 = off; off += align_up((size_t)a.n_frames * a.c * c.lp * es, 256);
     }
     c.xn = off;
-    if (a.ln_eps > 0.f) off += align_up((size_t)a.n_frames * a.s * a.c * es, 256);     // LayerNorm(x)
+    if (a.ln_eps > 0.f)                                   // LayerNorm(x), or only its row statistics when folded
+        off += align_up(a.ln_wq ? (size_t)a.n_frames * a.s * 2 * sizeof(float) : (size_t)a.n_frames * a.s * a.c * es, 256);
     c.kip = c.vtip = off;
     c.tp = round_up(a.ip ? a.t_ip : 0, 8);
     if (a.ip) {                                           // image keys / values^T of the IP-Adapter branch
@@ -131,6 +132,10 @@ int check_processor(const AidProcessorArgs& a) {
     if (a.ln_eps > 0.f) {
         if (!aid::layernorm_width_supported(a.c)) return AID_ERR_SHAPE;
         if ((a.ln_gamma && !aligned16(a.ln_gamma)) || (a.ln_beta && !aligned16(a.ln_beta))) return AID_ERR_SHAPE;
+        if (a.ln_wq) {                              // folded: the projections run on x itself with pre-multiplied weights
+            if (!a.ln_const || a.c % 64 || !aligned16(a.ln_wq)) return AID_ERR_SHAPE;
+            if (!a.ctx && (!a.ln_wk || !a.ln_wv || !aligned16(a.ln_wk) || !aligned16(a.ln_wv))) return AID_ERR_ARG;
+        }
     }
     return AID_OK;
 }
@@ -216,6 +221,11 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
         d.batch = q.batch;
         d.scale = q.scale == 0.f ? 1.f : q.scale;
         d.stride_a = q.stride_a; d.stride_b = q.stride_b; d.stride_c = q.stride_c;
+        if (q.ln_stats) {
+            if (!q.ln_colsum || !q.ln_shift || (q.ln_side != 1 && q.ln_side != 2) || q.stride_stats < 0) return AID_ERR_ARG;
+            d.ln_stats = q.ln_stats; d.ln_colsum = q.ln_colsum; d.ln_shift = q.ln_shift;
+            d.ln_side = q.ln_side; d.stride_stats = q.stride_stats;
+        }
     }
     double flops = 0, bytes = 0;
     if (g_prof_on) {
@@ -255,6 +265,30 @@ int aid_layernorm(const void* x, const void* gamma, const void* beta, void* y, i
         e = aid::layernorm_launch(x, gamma, beta, y, rows, c, eps, dtype, static_cast<hipStream_t>(stream));
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_layernorm");
+}
+
+int aid_ln_stats(const void* x, float* stats, int64_t rows, int32_t c, float eps, int32_t dtype, void* stream) {
+    if (!x || !stats || rows < 0 || !(eps >= 0.f)) return AID_ERR_ARG;
+    if (dtype != AID_DTYPE_F16 && dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (!aid::layernorm_width_supported(c) || !aligned16(x)) return AID_ERR_SHAPE;
+    hipError_t e;
+    {
+        ProfScope ps(static_cast<hipStream_t>(stream), dtype == AID_DTYPE_F16 ? "aid_ln_stats<f16>" : "aid_ln_stats<bf16>",
+                     4.0 * rows * c, 2.0 * rows * c + 8.0 * rows);
+        e = aid::ln_stats_launch(x, stats, rows, c, eps, dtype, static_cast<hipStream_t>(stream));
+    }
+    return e == hipSuccess ? AID_OK : fail_hip(e, "aid_ln_stats");
+}
+
+int aid_ln_fold(const void* w, const void* gamma, const void* beta, void* w_folded, float* colsum, float* shift,
+                int32_t rows, int32_t c, int32_t dtype, void* stream) {
+    if (!w || !w_folded || !colsum || !shift || rows < 1) return AID_ERR_ARG;
+    if (dtype != AID_DTYPE_F16 && dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (!aid::layernorm_width_supported(c)) return AID_ERR_SHAPE;
+    if (!aligned16(w) || !aligned16(w_folded) || (gamma && !aligned16(gamma)) || (beta && !aligned16(beta))) return AID_ERR_SHAPE;
+    const hipError_t e = aid::ln_fold_launch(w, gamma, beta, w_folded, colsum, shift, rows, c, dtype,
+                                             static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? AID_OK : fail_hip(e, "aid_ln_fold");
 }
 
 int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
@@ -332,7 +366,12 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     void* o = ws + cv.o;
     const bool cross = a.ctx != nullptr;
     const void* xin = a.x;
-    if (a.ln_eps > 0.f) {                      // 0. the block's norm1 / norm2 in front of the call
+    const bool folded = a.ln_eps > 0.f && a.ln_wq != nullptr;
+    float* stats = reinterpret_cast<float*>(ws + cv.xn);
+    if (folded) {                              // 0. the block's norm1 / norm2, folded: only the row statistics are computed
+        rc = aid_ln_stats(a.x, stats, (int64_t)a.n_frames * a.s, a.c, a.ln_eps, a.dtype, stream);
+        if (rc != AID_OK) return rc;
+    } else if (a.ln_eps > 0.f) {               // 0. ... or as its own pass
         void* xn = ws + cv.xn;
         rc = aid_layernorm(a.x, a.ln_gamma, a.ln_beta, xn, (int64_t)a.n_frames * a.s, a.c, a.ln_eps, a.dtype, stream);
         if (rc != AID_OK) return rc;
@@ -358,6 +397,18 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     pr[2].m = a.c; pr[2].n = l; pr[2].k = cc;
     pr[2].lda = cc; pr[2].ldb = cc; pr[2].ldc = cv.lp; pr[2].batch = nctx;
     pr[2].stride_a = 0; pr[2].stride_b = (int64_t)l * cc; pr[2].stride_c = (int64_t)a.c * cv.lp;
+    if (folded) {                                             // x W'^T with the LayerNorm applied in the epilogue
+        pr[0].b = a.ln_wq;
+        pr[0].ln_stats = stats; pr[0].ln_colsum = a.ln_const; pr[0].ln_shift = a.ln_const + a.c; pr[0].ln_side = 1;
+        if (!cross) {
+            pr[1].b = a.ln_wk;
+            pr[1].ln_stats = stats; pr[1].ln_colsum = a.ln_const + 2 * a.c; pr[1].ln_shift = a.ln_const + 3 * a.c;
+            pr[1].ln_side = 1;
+            pr[2].a = a.ln_wv;
+            pr[2].ln_stats = stats; pr[2].ln_colsum = a.ln_const + 4 * a.c; pr[2].ln_shift = a.ln_const + 5 * a.c;
+            pr[2].ln_side = 2; pr[2].stride_stats = l;
+        }
+    }
     int npr = 3;
     void* kip = ws + cv.kip;
     void* vtip = ws + cv.vtip;

@@ -33,6 +33,51 @@ struct TileCoord {
     int p, batch, m0, n0;
 };
 
+// Fence between the MAC loop and an epilogue.  hipcc's hazard recogniser counts the wait states between an MFMA and the
+// first VALU access of its result along the fall-through path; with a branch in between (`if (bias)`, `if (ln_side)`, a
+// row guard) the taken path can be shorter — the hazard that bit the ragged attention tile (profiles/r02_attn_notes.txt).
+// Nothing of the kind was observed here; 20 wait states per tile are cheap insurance.
+template <int NB, int MB>
+__device__ __forceinline__ void mfma_fence(f32x16 (&acc)[NB][MB]) {
+    // volatile asm statements keep their order: every MFMA (producer of an accumulator) sits above the first ties, the
+    // wait states between the two rows of ties, every use of an accumulator below the second
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) asm volatile("" : "+v"(acc[i][j]));
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) asm volatile("" : "+v"(acc[i][j]));
+}
+
+// Folded LayerNorm (GemmDesc.ln_*): acc = x . W'[row] with W' = W * gamma  ->  rstd * (acc - mean * colsum[row]) + shift[row].
+// `m`, `n` are the output coordinates of v[0]; v[e] sits at column n + e.  Reads are guarded, out-of-range entries are
+// never stored by the callers.
+__device__ __forceinline__ void ln_fix4(const GemmDesc& P, const float* __restrict__ stats, int m, int n, f32x4& v) {
+    if (P.ln_side == 1) {                               // statistics per output row, weight constants per column
+        const float mu = m < P.m ? stats[2 * m] : 0.f, rs = m < P.m ? stats[2 * m + 1] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int nn = n + e < P.n ? n + e : P.n - 1;
+            float t = fmaf(-mu, P.ln_colsum[nn], v[e]);
+            asm volatile("" : "+v"(t));                 // scalar on purpose, see Engine::store_tile
+            v[e] = fmaf(rs, t, P.ln_shift[nn]);
+        }
+    } else {                                            // the activation is the B operand: statistics per column
+        const int mm = m < P.m ? m : P.m - 1;
+        const float cs = P.ln_colsum[mm], sh = P.ln_shift[mm];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int nn = n + e < P.n ? n + e : P.n - 1;
+            float t = fmaf(-stats[2 * nn], cs, v[e]);
+            asm volatile("" : "+v"(t));
+            v[e] = fmaf(stats[2 * nn + 1], t, sh);
+        }
+    }
+}
+
 // Block -> (problem, batch, tile).  The hardware places block b on XCD b % 8; xcd_remap gives every XCD a
 // contiguous range of positions so neighbouring tiles share that XCD's L2.
 //  * problems with equal K loops are simply concatenated (each XCD then mostly streams ONE weight matrix);
@@ -176,6 +221,7 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_kernel(const GemmGroup g
     }
 
     // ---- epilogue: lane (m = l31, hi) holds n = 8*g + 4*hi + {0..3} for g = r>>2 -------------
+    mfma_fence(acc);
     const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
 #pragma unroll
     for (int im = 0; im < 2; ++im) {
@@ -189,7 +235,10 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_kernel(const GemmGroup g
                 if (n >= P.n) continue;
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[in][im][gq * 4 + e] * P.scale;
+                for (int e = 0; e < 4; ++e) v[e] = acc[in][im][gq * 4 + e];
+                if (P.ln_stats) ln_fix4(P, P.ln_stats + 2 * (int64_t)tc.batch * P.stride_stats, m, n, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= P.scale;
                 if (bias) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -233,7 +282,8 @@ struct Engine {
     static constexpr int STAGE = (BM + BN) * RB;               // bytes per stage
     static constexpr int DPT = IPA + IPB;                      // DMA instructions per wave per K tile
     static constexpr int CLD = BN + 8;                         // staged C row (elements)
-    static constexpr size_t SMEM = ((size_t)NS * STAGE > (size_t)BM * CLD * 2) ? (size_t)NS * STAGE : (size_t)BM * CLD * 2;
+    static constexpr size_t LNS = (size_t)(BM + BN) * 2 * sizeof(float);      // folded LayerNorm: per-row / per-column pairs of a tile
+    static constexpr size_t SMEM = ((size_t)NS * STAGE > (size_t)BM * CLD * 2 + LNS) ? (size_t)NS * STAGE : (size_t)BM * CLD * 2 + LNS;
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiles are multiples of 32x32");
     static_assert(BM % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "DMA instructions divide evenly over the waves");
     static_assert(NS >= 2 && NS <= 8, "ring depth");
@@ -354,15 +404,48 @@ struct Engine {
 
     // acc (+bias) -> LDS C tile -> coalesced 16-B row segments.  Ends with all stores drained and a barrier.
     // `R` (optional, laid out like C) is added after the rounding to T — the transformer block's residual add.
-    __device__ __forceinline__ void store_tile(const GemmDesc& P, T* C, int m0, int n0, const T* R = nullptr) {
+    __device__ __forceinline__ void store_tile(const GemmDesc& P, T* C, int m0, int n0, const T* R = nullptr,
+                                               const float* stats = nullptr) {
         T* Cs = reinterpret_cast<T*>(smem);        // [BM][CLD]
+        mfma_fence(acc);
         const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
         const bool bias_vec = (reinterpret_cast<uintptr_t>(bias) & 7) == 0;
+        // folded LayerNorm: the tile's per-row and per-column pairs go through LDS (behind the C tile) — one coalesced load
+        // per thread instead of 8 broadcast loads per 4-column group; ln_side 1: rows carry (mean, rstd), columns
+        // (colsum, shift); ln_side 2: the other way round
+        float lr0[MB], lr1[MB];
+        const int side = stats ? P.ln_side : 0;
+        float* const lnr = reinterpret_cast<float*>(smem + (size_t)BM * CLD * 2);     // [BM][2]
+        float* const lnc = lnr + 2 * BM;                                              // [BN][2]
+        if (side) {
+            for (int i = tid; i < BM + BN; i += NTHR) {
+                const bool isrow = i < BM;
+                const int g = isrow ? min(m0 + i, P.m - 1) : min(n0 + i - BM, P.n - 1);
+                float q0, q1;
+                if (isrow == (side == 1)) { q0 = stats[2 * g]; q1 = stats[2 * g + 1]; }
+                else                      { q0 = P.ln_colsum[g]; q1 = P.ln_shift[g]; }
+                lnr[2 * i] = q0;                        // lnc follows lnr: index i runs through both
+                lnr[2 * i + 1] = q1;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int im = 0; im < MB; ++im) {
+                lr0[im] = lnr[2 * (wm + im * 32 + l31)];
+                lr1[im] = lnr[2 * (wm + im * 32 + l31) + 1];
+            }
+        }
 #pragma unroll
         for (int in = 0; in < NB; ++in)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int nl = wn + in * 32 + gq * 8 + hi * 4;
+                f32x4 lc0 = {0.f, 0.f, 0.f, 0.f}, lc1 = {0.f, 0.f, 0.f, 0.f};
+                if (side) {
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(lnc + 2 * nl);          // pairs of columns nl, nl + 1
+                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(lnc + 2 * nl + 4);      // nl + 2, nl + 3
+                    lc0[0] = p0[0]; lc1[0] = p0[1]; lc0[1] = p0[2]; lc1[1] = p0[3];
+                    lc0[2] = p1[0]; lc1[2] = p1[1]; lc0[3] = p1[2]; lc1[3] = p1[3];
+                }
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                 if (bias) {
                     if (bias_vec && n0 + nl + 4 <= P.n) {
@@ -377,7 +460,29 @@ struct Engine {
                 for (int im = 0; im < MB; ++im) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[in][im][gq * 4 + e], P.scale, bv[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = acc[in][im][gq * 4 + e];
+                    // Scalar FMAs on purpose (the empty asm keeps hipcc from pairing them): as v_pk_fma_f32 with an
+                    // op_sel broadcast of the odd register of the (lr0[0], lr0[1]) pair, the product of the FIRST FMA
+                    // sporadically came out as 0 in lanes 48-63 of the low half — ~2e-5 of the outputs of a
+                    // 57344 x 640 x 640 problem, different elements every run (found by the parity test of this epilogue;
+                    // wait states, vmcnt(0), uncached loads and LDS staging of the operands all left it in place).
+                    if (side == 1) {                    // rstd_m (acc - mean_m colsum_n) + shift_n
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = fmaf(-lr0[im], lc0[e], v[e]);
+                            asm volatile("" : "+v"(t));
+                            v[e] = fmaf(lr1[im], t, lc1[e]);
+                        }
+                    } else if (side == 2) {             // rstd_n (acc - mean_n colsum_m) + shift_m
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = fmaf(-lc0[e], lr0[im], v[e]);
+                            asm volatile("" : "+v"(t));
+                            v[e] = fmaf(lc1[e], t, lr1[im]);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], P.scale, bv[e]);
                     *reinterpret_cast<T4*>(Cs + (wm + im * 32 + l31) * CLD + nl) = cvt4<T>(v);
                 }
             }
@@ -628,7 +733,8 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         e.set_tile(P, A, B, m0, n0);
         e.zero_acc();
         e.mac(0, P.k / 64);
-        e.store_tile(P, C, m0, n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)batch * P.stride_c : nullptr);
+        e.store_tile(P, C, m0, n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)batch * P.stride_c : nullptr,
+                     P.ln_stats ? P.ln_stats + 2 * (int64_t)batch * P.stride_stats : nullptr);
         return;
     }
     const int b = blockIdx.x - sd.pad_tiles;
@@ -643,7 +749,8 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         e.set_tile(P, A, B, tc.m0, tc.n0);
         e.zero_acc();
         e.mac(0, P.k / 64);
-        e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr);
+        e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr,
+                     P.ln_stats ? P.ln_stats + 2 * (int64_t)tc.batch * P.stride_stats : nullptr);
     } else {
         const int u = b - n_big;                                   // n_big is a multiple of 8: u % 8 is still the XCD
         const int n_rest = ((int)gridDim.x - sd.pad_tiles - n_big) >> 2;
@@ -661,7 +768,8 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         e.set_tile(P, A, B, tc.m0, tc.n0);
         e.zero_acc();
         e.mac(0, P.k / 64);
-        e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr);
+        e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr,
+                     P.ln_stats ? P.ln_stats + 2 * (int64_t)tc.batch * P.stride_stats : nullptr);
     }
 }
 
@@ -679,7 +787,8 @@ __global__ __launch_bounds__(WM * WN * 64) void aid_gemm_nt_pipe_kernel(const Ge
     e.set_tile(P, A, B, tc.m0, tc.n0);
     e.zero_acc();
     e.mac(0, P.k / BK);
-    e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr);
+    e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr,
+                     P.ln_stats ? P.ln_stats + 2 * (int64_t)tc.batch * P.stride_stats : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

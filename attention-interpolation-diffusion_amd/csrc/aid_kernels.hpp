@@ -17,6 +17,14 @@ struct GemmDesc {
     int32_t batch;
     float   scale;                                    // C = scale * A B^T + bias
     int64_t stride_a, stride_b, stride_c;
+    // LayerNorm folded into the projection (AidGemmProblem.ln_*): the weight operand holds W' = W * gamma, the epilogue
+    // turns  x W'^T  into  LayerNorm(x) W^T = rstd (x W'^T - mean * colsum) + shift
+    const float* ln_stats;                            // [activation rows, 2] = (mean, rstd); NULL = no LayerNorm
+    const float* ln_colsum;                           // [weight rows]  sum_k W'[row, k]
+    const float* ln_shift;                            // [weight rows]  sum_k beta[k] W[row, k]
+    int32_t ln_side;                                  // 1: the activation is A (statistics by m), 2: it is B (by n)
+    int32_t reserved;
+    int64_t stride_stats;                             // activation rows per batch
 };
 
 struct GemmGroup {                        // passed by value as the kernel argument
@@ -48,6 +56,9 @@ hipError_t lerp_kv_launch(const void* k, const void* vt, void* k2, void* vt2, co
 const char* attn_variant_name(const AidAttnArgs& a);   // thread-local buffer
 hipError_t layernorm_launch(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int c, float eps,
                             int dtype, hipStream_t stream);
+hipError_t ln_stats_launch(const void* x, float* stats, int64_t rows, int c, float eps, int dtype, hipStream_t stream);
+hipError_t ln_fold_launch(const void* w, const void* gamma, const void* beta, void* w_folded, float* colsum, float* shift,
+                          int rows, int c, int dtype, hipStream_t stream);
 bool       layernorm_width_supported(int c);
 
 }  // namespace aid

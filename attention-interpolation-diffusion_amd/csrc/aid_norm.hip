@@ -74,6 +74,111 @@ __global__ __launch_bounds__(256) void aid_layernorm_kernel(const T* __restrict_
     }
 }
 
+// ---- LayerNorm folded into the projections that consume it -----------------------------------------------------------
+//   LayerNorm(x) W^T = rstd (x W'^T - mean * colsum) + shift,   W' = W * gamma (rounded to the storage type),
+//   colsum[n] = sum_k W'[n, k]  (of the ROUNDED W', so the identity holds for the numbers the GEMM multiplies),
+//   shift[n]  = sum_k beta[k] W[n, k].
+// aid_ln_stats_kernel reads the activations once and writes (mean, rstd) per row — the normalised tensor is never
+// materialised (the separate LayerNorm kernel writes and the projection re-reads [rows, c]); aid_ln_fold_kernel prepares
+// the weight side once per (weights, gamma, beta).  Same statistics arithmetic as aid_layernorm_kernel above.
+template <typename T>
+__global__ __launch_bounds__(256) void aid_ln_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int64_t rows,
+                                                           int c, float eps) {
+    typedef typename Vec<T>::v8 T8;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = c >> 3;
+    const T* xr = x + row * c;
+    f32x8 v[LN_MAX_CHUNKS];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            v[i] = up8<T>(*reinterpret_cast<const T8*>(xr + ch * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                q = fmaf(d, d, q);
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void aid_ln_fold_kernel(const T* __restrict__ w, const T* __restrict__ gamma,
+                                                          const T* __restrict__ beta, T* __restrict__ wf,
+                                                          float* __restrict__ colsum, float* __restrict__ shift, int rows, int c) {
+    typedef typename Vec<T>::v8 T8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float cs = 0.f, sh = 0.f;
+    for (int ch = lane; ch < (c >> 3); ch += 64) {
+        const f32x8 wv = up8<T>(*reinterpret_cast<const T8*>(w + (int64_t)row * c + ch * 8));
+        f32x8 g, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[e] = 1.f; b[e] = 0.f; }
+        if (gamma) g = up8<T>(*reinterpret_cast<const T8*>(gamma + ch * 8));
+        if (beta) b = up8<T>(*reinterpret_cast<const T8*>(beta + ch * 8));
+        f32x8 p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = wv[e] * g[e];
+        const T8 pr = cvt8<T>(p);
+        *reinterpret_cast<T8*>(wf + (int64_t)row * c + ch * 8) = pr;
+        const f32x8 pf = up8<T>(pr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cs += pf[e];
+            sh = fmaf(b[e], wv[e], sh);
+        }
+    }
+    cs = wave_sum(cs);
+    sh = wave_sum(sh);
+    if (lane == 0) {
+        colsum[row] = cs;
+        shift[row] = sh;
+    }
+}
+
+hipError_t ln_stats_launch(const void* x, float* stats, int64_t rows, int c, float eps, int dtype, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == AID_DTYPE_F16)
+        hipLaunchKernelGGL(aid_ln_stats_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)x, stats, rows, c, eps);
+    else
+        hipLaunchKernelGGL(aid_ln_stats_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)x, stats, rows, c, eps);
+    return hipGetLastError();
+}
+
+hipError_t ln_fold_launch(const void* w, const void* gamma, const void* beta, void* w_folded, float* colsum, float* shift,
+                          int rows, int c, int dtype, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == AID_DTYPE_F16)
+        hipLaunchKernelGGL(aid_ln_fold_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)w, (const f16*)gamma,
+                           (const f16*)beta, (f16*)w_folded, colsum, shift, rows, c);
+    else
+        hipLaunchKernelGGL(aid_ln_fold_kernel<bf16>, grid, dim3(256), 0, stream, (const bf16*)w, (const bf16*)gamma,
+                           (const bf16*)beta, (bf16*)w_folded, colsum, shift, rows, c);
+    return hipGetLastError();
+}
+
 bool layernorm_width_supported(int c) { return c >= 8 && c % 8 == 0 && c <= 64 * 8 * LN_MAX_CHUNKS; }
 
 hipError_t layernorm_launch(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int c, float eps,

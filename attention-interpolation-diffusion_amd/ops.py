@@ -123,7 +123,15 @@ def gemm_nt(problems: Sequence[dict]) -> None:
         q.m, q.n, q.k = p["m"], p["n"], p["k"]
         q.lda, q.ldb, q.ldc = p["lda"], p["ldb"], p["ldc"]
         q.batch = p.get("batch", 1)
+        q.scale = float(p.get("scale", 0.0))            # 0 = 1 (zero-initialised structs)
         q.stride_a, q.stride_b, q.stride_c = p.get("stride_a", 0), p.get("stride_b", 0), p.get("stride_c", 0)
+        if p.get("ln_stats") is not None:       # folded LayerNorm: dict(ln_stats=, ln_colsum=, ln_shift=, ln_side=1|2[, stride_stats=])
+            for t_ in (p["ln_stats"], p["ln_colsum"], p["ln_shift"]):
+                _require_gpu(t_)
+                if t_.dtype != torch.float32 or not t_.is_contiguous():
+                    raise TypeError("ln_stats / ln_colsum / ln_shift are contiguous float32 tensors")
+            q.ln_stats, q.ln_colsum, q.ln_shift = p["ln_stats"].data_ptr(), p["ln_colsum"].data_ptr(), p["ln_shift"].data_ptr()
+            q.ln_side, q.stride_stats = int(p["ln_side"]), int(p.get("stride_stats", 0))
     with _on(problems[0]["a"].device):
         _lib.check(lib.aid_gemm_nt(arr, n, dt, _stream()), "aid_gemm_nt")
 
@@ -159,6 +167,37 @@ def layernorm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optio
         _lib.check(_lib.load().aid_layernorm(x.data_ptr(), _ptr(gamma), _ptr(beta), out.data_ptr(), x.numel() // c, c,
                                              float(eps), _dtype_code(x), _stream()), "aid_layernorm")
     return out
+
+
+def ln_stats(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """(mean, rstd) per row of x over the last dimension, fp32 [rows, 2] — what the folded LayerNorm needs of x."""
+    _require_gpu(x)
+    if not x.is_contiguous():
+        raise ValueError("operands must be contiguous")
+    c = x.shape[-1]
+    st = torch.empty(x.numel() // c, 2, dtype=torch.float32, device=x.device)
+    with _on(x.device):
+        _lib.check(_lib.load().aid_ln_stats(x.data_ptr(), st.data_ptr(), x.numel() // c, c, float(eps), _dtype_code(x),
+                                            _stream()), "aid_ln_stats")
+    return st
+
+
+def ln_fold(w: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor]):
+    """Fold a LayerNorm's affine part into the Linear that consumes it: returns (w * gamma in the storage dtype,
+    colsum fp32 [rows], shift fp32 [rows]) — see AidGemmProblem.ln_* in include/aid_hip.h."""
+    _require_gpu(w, gamma, beta)
+    if w.ndim != 2 or not w.is_contiguous():
+        raise ValueError("w must be a contiguous [rows, c] weight")
+    for t_ in (gamma, beta):
+        if t_ is not None and (t_.dtype != w.dtype or t_.numel() != w.shape[1] or not t_.is_contiguous()):
+            raise ValueError("gamma / beta must be contiguous [c] tensors of the weight dtype")
+    wf = torch.empty_like(w)
+    cs = torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
+    sh = torch.empty_like(cs)
+    with _on(w.device):
+        _lib.check(_lib.load().aid_ln_fold(w.data_ptr(), _ptr(gamma), _ptr(beta), wf.data_ptr(), cs.data_ptr(), sh.data_ptr(),
+                                           w.shape[0], w.shape[1], _dtype_code(w), _stream()), "aid_ln_fold")
+    return wf, cs, sh
 
 
 def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, extra_rows: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -248,14 +287,17 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
                   out: Optional[torch.Tensor] = None, n_plain: int = 0,
                   ln: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor], float]] = None,
                   residual: Optional[torch.Tensor] = None, seg_executed: int = 0,
-                  ip: Optional[dict] = None) -> torch.Tensor:
+                  ip: Optional[dict] = None, ln_folded: Optional[tuple] = None) -> torch.Tensor:
     """One whole processor call: y = to_out(AID-attention(to_q(x), to_k(ctx), to_v(ctx)))
     in three launches (grouped q/k/V^T GEMM, attention core, out-proj GEMM).
     ``ln = (gamma, beta, eps)`` computes on LayerNorm(x); ``residual`` is added to the result (the transformer
     block's norm in front of the call and its residual add after it).
     ``ip`` = the IP-Adapter image branch (AidProcessorArgs.ip_*): dict(tokens=[R, T, Cc] tensor whose rows may be a
     strided view, wk=to_k_ip weight, wv=to_v_ip weight, mode="same"|"plain", scale=float, map=int32 device [N] or None,
-    frame_scale=fp32 device [N] or None, begin=int, end=int)."""
+    frame_scale=fp32 device [N] or None, begin=int, end=int).
+    ``ln_folded`` = (wq', wk', wv', const) with ``ln``: the LayerNorm is folded into the projections (wq' etc. from
+    ``ln_fold``, wk' / wv' None for cross-attention, const fp32 [6, C] = colsum_q, shift_q, colsum_k, shift_k, colsum_v,
+    shift_v): only the row statistics of x are computed, LayerNorm(x) is never written."""
     lib = _lib.load()
     ipt = ip or {}
     dev = _require_gpu(x, ctx, wq, wk, wv, wo, bo, coef, ctx_map, out, residual, *(ln[:2] if ln else ()),
@@ -309,6 +351,19 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
             if t_ is not None and (t_.dtype != x.dtype or t_.numel() != c or not t_.is_contiguous()):
                 raise ValueError("LayerNorm gamma / beta must be contiguous [c] tensors of the activation dtype")
         a.ln_gamma, a.ln_beta, a.ln_eps = _ptr(g_), _ptr(b_), float(eps)
+        if ln_folded is not None:
+            fq, fk, fv, cst = ln_folded
+            _require_gpu(fq, fk, fv, cst)
+            if cst.dtype != torch.float32 or tuple(cst.shape) != (6, c) or not cst.is_contiguous():
+                raise ValueError("ln_folded constants must be a contiguous float32 [6, C] tensor")
+            for t_, ref in ((fq, wq), (fk, wk), (fv, wv)):
+                if t_ is not None and (t_.dtype != x.dtype or t_.shape != ref.shape or not t_.is_contiguous()):
+                    raise ValueError("folded weights must look like the weights they replace")
+            if ctx is None and (fk is None or fv is None):
+                raise ValueError("self-attention needs the folded to_k / to_v weights too")
+            a.ln_wq, a.ln_wk, a.ln_wv, a.ln_const = fq.data_ptr(), _ptr(fk), _ptr(fv), cst.data_ptr()
+    elif ln_folded is not None:
+        raise ValueError("ln_folded goes with ln=(gamma, beta, eps)")
     if residual is not None:
         if residual.shape != x.shape or residual.dtype != x.dtype or not residual.is_contiguous():
             raise ValueError("residual must be a contiguous tensor shaped like the hidden states")

@@ -21,6 +21,9 @@ Differences from the reference that are deliberate and documented:
 """
 from __future__ import annotations
 
+import os
+import weakref
+
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -98,9 +101,9 @@ class InterpolatedAttnProcessor(nn.Module):
     def fused_sublayer(self, attn, norm, hidden_states, encoder_hidden_states=None, ctx_index=None):
         """``hidden_states + attn(norm(hidden_states), encoder_hidden_states)`` — what diffusers' BasicTransformerBlock
         computes around attn1 / attn2 (LayerNorm, processor call, residual add) — in ONE library call: the LayerNorm
-        runs as a HIP kernel in front of the projections and the residual is added in the epilogue of the out
-        projection (after its rounding, so the result is bit-identical to the three separate steps on the same
-        kernels).  Falls back to the three steps where the one-call form does not apply (a wrapped foreign
+        is folded into the projections (only its row statistics are computed; LayerNorm(x) is never written — or, for
+        widths the fold does not cover, it runs as a HIP kernel in front of them) and the residual is added in the
+        epilogue of the out projection, after its rounding like the block's separate add.  Falls back to the three steps where the one-call form does not apply (a wrapped foreign
         ``original_attn``, 4-D inputs, Attention extras)."""
         if self._mode is None:
             raise NotImplementedError("fused_sublayer is implemented for the text processors (outer / inner)")
@@ -111,7 +114,8 @@ class InterpolatedAttnProcessor(nn.Module):
         ctx_index = self.ctx_index if ctx_index is None else ctx_index
         hidden_states = hidden_states.contiguous()
         return _run_text(self, attn, hidden_states, encoder_hidden_states, None, None,
-                         self._mode if self.activated else "plain", ctx_index, ln=_ln_of(norm), add_to=hidden_states)
+                         self._mode if self.activated else "plain", ctx_index, ln=_ln_of(norm), add_to=hidden_states,
+                         ln_folded=_ln_folded(attn, norm, encoder_hidden_states is not None))
 
     # ---- build-specific helpers ------------------------------------------------------------
     def _coef_device(self, device: torch.device, dtype: torch.dtype, batch: int) -> torch.Tensor:
@@ -234,6 +238,35 @@ def _ln_of(norm) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], float]
     return norm.weight, norm.bias, float(norm.eps)
 
 
+# Folded LayerNorm (include/aid_hip.h "aid_ln_fold"): per attention module, the projection weights
+# pre-multiplied by the LayerNorm's gamma plus the two fp32 constant vectors per projection.  Rebuilt when a weight, gamma
+# or beta tensor is replaced or edited in place (data_ptr + _version).  AID_LN_FOLD=0 keeps the LayerNorm as its own pass.
+_FOLD_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _ln_folded(attn, norm, cross: bool):
+    """(wq', wk', wv', const [6, C]) for ops.processor_fwd(ln_folded=...), or None where folding does not apply."""
+    if os.environ.get("AID_LN_FOLD", "1") == "0":
+        return None
+    wq, wk, wv, _, _ = _weights(attn)
+    c = wq.shape[1]
+    if c % 64 or (not cross and (wk.shape[1] != c or wv.shape[1] != c)):
+        return None
+    srcs = (wq, norm.weight, norm.bias) if cross else (wq, wk, wv, norm.weight, norm.bias)
+    key = (cross,) + tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs)
+    ent = _FOLD_CACHE.get(attn)
+    if ent is None or ent[0] != key:
+        const = torch.zeros(6, wq.shape[0], dtype=torch.float32, device=wq.device)
+        fq, const[0], const[1] = ops.ln_fold(wq, norm.weight, norm.bias)
+        fk = fv = None
+        if not cross:
+            fk, const[2], const[3] = ops.ln_fold(wk, norm.weight, norm.bias)
+            fv, const[4], const[5] = ops.ln_fold(wv, norm.weight, norm.bias)
+        ent = (key, (fq, fk, fv, const))
+        _FOLD_CACHE[attn] = ent
+    return ent[1]
+
+
 def _plain_sublayer_ok(attn, hidden_states) -> bool:
     """The one-call form  h + attn(norm(h))  covers the transformer-block attention of SD / SDXL: 3-D input and none of
     the Attention extras (spatial / group norm, own residual connection, output rescale, cross-attention norm)."""
@@ -243,7 +276,7 @@ def _plain_sublayer_ok(attn, hidden_states) -> bool:
 
 
 def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidden_states,
-              attention_mask, temb, mode: str, ctx_index=None, ln=None, add_to=None):
+              attention_mask, temb, mode: str, ctx_index=None, ln=None, add_to=None, ln_folded=None):
     residual, x, ctx, shape4 = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
     wq, wk, wv, wo, bo = _weights(attn)
     coef = vals = None
@@ -283,7 +316,7 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
     fused = proc.is_fused if mode != "plain" else False
     y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode, fused=fused, coef=coef,
                           begin=begin, end=end, ctx_map=ctx_map,
-                          n_plain=proc.plain_tail if mode != "plain" else 0, ln=ln, residual=add_to,
+                          n_plain=proc.plain_tail if mode != "plain" else 0, ln=ln, residual=add_to, ln_folded=ln_folded,
                           seg_executed=ops.executed_segments(mode, fused, vals, x.shape[0], idx, begin, end))
     return _epilogue(attn, y, residual, shape4)
 
@@ -310,7 +343,7 @@ class HipAttnProcessor:
         elif ctx is not None:
             ctx = ctx.contiguous()
         return ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map,
-                                 ln=_ln_of(norm), residual=x)
+                                 ln=_ln_of(norm), residual=x, ln_folded=_ln_folded(attn, norm, ctx is not None))
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  *args, ctx_index=None, **kwargs):

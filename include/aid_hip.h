@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AID_ABI_VERSION 3
+#define AID_ABI_VERSION 4
 
 /* element types of activations / weights (accumulation is always fp32) */
 #define AID_DTYPE_F16  0
@@ -86,6 +86,18 @@ typedef struct AidGemmProblem {
     float       scale;         /* C = scale * (A B^T) + bias; 0 means 1 (zero-initialised structs)  */
     int64_t     stride_a, stride_b, stride_c;   /* per-batch strides in elements (0 = shared) */
     const void* residual;      /* NULL = none; [m, ldc] per batch like C, operand dtype               */
+    /* LayerNorm folded into the projection (ln_stats == NULL: none).  The ACTIVATION operand is un-normalised x, the     */
+    /* WEIGHT operand is W' = W * gamma (aid_ln_fold), and the epilogue computes, before `scale` and `bias`,              */
+    /*     LayerNorm(x) W^T = rstd * (x W'^T - mean * ln_colsum) + ln_shift                                               */
+    /* ln_side 1: A is the activation (statistics row m, weight constants column n); 2: B is (statistics by n, constants  */
+    /* by m — the V^T = Wv x^T problem).  ln_stats: fp32 [activation rows, 2] = (mean, rstd) from aid_ln_stats, batch b   */
+    /* starts at row b * stride_stats; ln_colsum / ln_shift: fp32 [weight rows] from aid_ln_fold.                          */
+    const float* ln_stats;
+    const float* ln_colsum;
+    const float* ln_shift;
+    int32_t      ln_side;
+    int32_t      reserved0;
+    int64_t      stride_stats;
 } AidGemmProblem;
 
 int aid_gemm_nt(const AidGemmProblem* problems /* host */, int n_problems, int dtype, void* stream);
@@ -98,6 +110,15 @@ int aid_gemm_nt(const AidGemmProblem* problems /* host */, int n_problems, int d
  * ------------------------------------------------------------------------------------- */
 int aid_layernorm(const void* x, const void* gamma, const void* beta, void* y, int64_t rows, int32_t c,
                   float eps, int32_t dtype, void* stream);
+
+/* The same LayerNorm FOLDED into the projections that consume it, so that LayerNorm(x) is never written or re-read:
+ *   aid_ln_stats   stats[r] = (mean_r, rsqrt(var_r + eps)), fp32 [rows, 2] — one read of x, same arithmetic as aid_layernorm
+ *   aid_ln_fold    once per (weight, gamma, beta): w_folded = w * gamma (storage dtype), colsum[n] = sum_k w_folded[n, k],
+ *                  shift[n] = sum_k beta[k] w[n, k]   (fp32 [rows]); w is [rows, c] = torch Linear.weight
+ * and AidGemmProblem.ln_* applies  rstd (x W'^T - mean colsum) + shift  in the GEMM epilogue.  Requirements as aid_layernorm. */
+int aid_ln_stats(const void* x, float* stats, int64_t rows, int32_t c, float eps, int32_t dtype, void* stream);
+int aid_ln_fold(const void* w, const void* gamma, const void* beta, void* w_folded, float* colsum, float* shift,
+                int32_t rows, int32_t c, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Interpolated attention core on projected tensors.
@@ -167,7 +188,7 @@ int aid_lerp_kv(const void* k, const void* vt, void* k2, void* vt2, const float*
  *   x   [n_frames, s, c]   hidden states          ctx [n_frames, l, cc] or NULL (self-attn: ctx = x)
  *   wq [c, c]  wk [c, cc]  wv [c, cc]  wo [c, c]  bo [c]      (torch Linear.weight layout [out, in])
  *   y   [n_frames, s, c]   = to_out( AID-attention( to_q(x), to_k(ctx), to_v(ctx) ) )
- * Launches: [1 LayerNorm,] 1 grouped GEMM (q, k, V^T [, K_ip, V_ip^T]), [INNER: 1 streaming K/V lerp,] 1 attention
+ * Launches: [1 LayerNorm or 1 row-statistics pass,] 1 grouped GEMM (q, k, V^T [, K_ip, V_ip^T]), [INNER: 1 streaming K/V lerp,] 1 attention
  * kernel [+ 1 for the image branch, accumulating], 1 GEMM (out-proj + bias [+ residual]).
  * Optional block-level fusion: with ln_eps > 0 the call computes on LayerNorm(x) (the block's
  * norm1 / norm2; self-attention keys / values use the normalised x too, a cross-attention ctx is left alone), and
@@ -221,6 +242,14 @@ typedef struct AidProcessorArgs {
     int32_t ip_begin, ip_end;    /* AID_IP_SAME: image rows of the end-point frames           */
     int32_t seg_executed;        /* accounting, see AidAttnArgs.seg_executed (text launch only) */
     int32_t reserved0;
+    /* ---- folded LayerNorm (ln_eps > 0 and ln_wq != NULL): the call runs aid_ln_stats on x instead of aid_layernorm and  */
+    /* projects x with the folded weights (aid_ln_fold of wq / wk / wv with ln_gamma / ln_beta; wk / wv only for           */
+    /* self-attention, a cross-attention ctx is not normalised).  ln_const: fp32 [6, c] = colsum_q, shift_q, colsum_k,     */
+    /* shift_k, colsum_v, shift_v.  Needs c % 64 == 0 (the projections then run on the k % 64 == 0 engines).               */
+    const void*  ln_wq;
+    const void*  ln_wk;
+    const void*  ln_wv;
+    const float* ln_const;
 } AidProcessorArgs;
 
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args /* host */);

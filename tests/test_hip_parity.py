@@ -524,7 +524,12 @@ def test_gemm_residual_equals_the_separate_add(dtype, mnk):
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
 @pytest.mark.parametrize("kind", ["outer", "inner", "plain"])
 @pytest.mark.parametrize("cross", [False, True], ids=["self", "cross"])
-def test_fused_sublayer_equals_norm_call_add(dtype, kind, cross):
+@pytest.mark.parametrize("fold", ["0", "1"], ids=["ln_kernel", "ln_folded"])
+def test_fused_sublayer_equals_norm_call_add(dtype, kind, cross, fold, monkeypatch):
+    """h + attn(norm(h)) in one library call.  With the LayerNorm as its own pass (AID_LN_FOLD=0) the result is bit-identical
+    to the three steps on the same kernels; folded into the projections (default) it is a different rounding path
+    (x W'^T corrected in the epilogue instead of round(LayerNorm(x)) W^T) and is held against the fp64 oracle only."""
+    monkeypatch.setenv("AID_LN_FOLD", fold)
     n, s, heads, d, l, cc = 5, 200, 2, 64, 77, 96
     c = heads * d
     g = torch.Generator().manual_seed(77 + int(cross))
@@ -544,7 +549,10 @@ def test_fused_sublayer_equals_norm_call_add(dtype, kind, cross):
     fused = proc.fused_sublayer(attn, norm, h, ctx)
     xn = ops.layernorm(h, norm.weight, norm.bias, norm.eps)
     steps = h + proc(attn, xn, encoder_hidden_states=ctx)                    # the three steps on the same kernels
-    assert torch.equal(fused, steps)
+    if fold == "0":
+        assert torch.equal(fused, steps)
+    else:
+        assert not torch.equal(fused, steps) and rel_l2(to_np64(fused), to_np64(steps)) < TOL[dtype]
     # against the oracle: h + attention(LayerNorm(h)) for the AID half and one rider frame
     w = O.AttnWeights(*(to_np64(t) for t in (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
                                               attn.to_out[0].weight, attn.to_out[0].bias)), heads)
@@ -564,6 +572,48 @@ def test_fused_sublayer_equals_norm_call_add(dtype, kind, cross):
         proc.deactivate()
         proc.original_attn = lambda a_, x_, e_=None, m_=None, t_=None: aid_amd.HipAttnProcessor()(a_, x_, e_)
         assert torch.equal(proc.fused_sublayer(attn, norm, h, ctx), h + aid_amd.HipAttnProcessor()(attn, norm(h), ctx))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("mnk", [(14336, 1280, 1280), (3000, 640, 320), (57344, 640, 640), (300, 200, 128), (257, 324, 72)],
+                         ids=lambda t: "m%d_n%d_k%d" % t)
+def test_gemm_with_folded_layernorm_vs_oracle(dtype, mnk):
+    """LayerNorm(x) W^T computed as rstd (x W'^T - mean colsum) + shift in the GEMM epilogue — both operand sides (q / k:
+    the activation is A; V^T = Wv x^T: it is B, batched per frame), all three engines (ping-pong, lock-step, ragged k),
+    with scale and bias on top.  x has a mean of several sigma so the cancellation in the correction is exercised."""
+    m, n, k = mnk
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) * 1.5 + 2.0).to(dtype)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype)
+    gamma = (1.0 + 0.3 * torch.randn(k, generator=g)).to(dtype)
+    beta = (0.2 * torch.randn(k, generator=g)).to(dtype)
+    bias = torch.randn(n, generator=g).to(dtype)
+    eps = 1e-5
+    xd, wd = x.to(DEV), w.to(DEV)
+    st = ops.ln_stats(xd, eps)
+    x64 = to_np64(x)
+    assert np.allclose(to_np64(st[:, 0]), x64.mean(1), rtol=1e-5, atol=1e-5)
+    assert np.allclose(to_np64(st[:, 1]), 1.0 / np.sqrt(x64.var(1) + eps), rtol=1e-4)
+    wf, cs, sh = ops.ln_fold(wd, gamma.to(DEV), beta.to(DEV))
+    assert torch.equal(wf, (wd.float() * gamma.to(DEV).float()).to(dtype))
+    assert np.allclose(to_np64(cs), to_np64(wf).sum(1), rtol=1e-5, atol=1e-4)
+    assert np.allclose(to_np64(sh), to_np64(w) @ to_np64(beta), rtol=1e-5, atol=1e-4)
+    ref = O.layer_norm(x64, to_np64(gamma), to_np64(beta), eps) @ to_np64(w).T
+    # side 1: y = 0.5 * LayerNorm(x) W^T + bias
+    y = torch.empty(m, n, dtype=dtype, device=DEV)
+    ops.gemm_nt([dict(a=xd, b=wf, c=y, bias=bias.to(DEV), m=m, n=n, k=k, lda=k, ldb=k, ldc=n, scale=0.5,
+                      ln_stats=st, ln_colsum=cs, ln_shift=sh, ln_side=1)])
+    assert rel_l2(to_np64(y), 0.5 * ref + to_np64(bias)) < TOL_GEMM[dtype], ops.last_gemm_variant()
+    # side 2: per "frame" f of rows, Y_f^T = W LayerNorm(x_f)^T  ([n, rows] per batch, padded row stride)
+    frames = 4 if m % 4 == 0 else 1
+    rows = m // frames
+    ldc = (rows + 7) // 8 * 8
+    yt = torch.zeros(frames, n, ldc, dtype=dtype, device=DEV)
+    ops.gemm_nt([dict(a=wf, b=xd, c=yt, m=n, n=rows, k=k, lda=k, ldb=k, ldc=ldc, batch=frames, stride_a=0,
+                      stride_b=rows * k, stride_c=n * ldc, ln_stats=st, ln_colsum=cs, ln_shift=sh, ln_side=2,
+                      stride_stats=rows)])
+    got = to_np64(yt)[:, :, :rows].transpose(0, 2, 1).reshape(m, n)
+    assert rel_l2(got, ref) < TOL_GEMM[dtype], ops.last_gemm_variant()
 
 
 # ------------------------------------------------------------------------------------------------
