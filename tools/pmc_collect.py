@@ -37,17 +37,20 @@ PASSES = [
 def bench_name(sym):
     """kernel symbol -> the name bench.py's roofline object uses"""
     dt = "bf16" if "IDF16b" in sym else "f16"
-    m = re.search(r"aid_attn_kernelIDF16b?_?Li(\d+)ELi(\d)ELi(\d)ELi(\d)", sym)
+    m = re.search(r"aid_attn_kernelIDF16b?_?Li(\d+)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)", sym)
     if m:
-        qb = ",qb2" if m.group(4) == "2" else ""
-        return f"aid_attn<{dt},d{m.group(1)},{MODES[m.group(2)]},nw{m.group(3)}{qb}>"
+        if m.group(6) == "1":
+            return f"aid_attn<{dt},d{m.group(1)},{MODES[m.group(2)]},res>"
+        sfx = ",qb2" if m.group(4) == "2" else ",pipe" if m.group(5) == "1" else ""
+        return f"aid_attn<{dt},d{m.group(1)},{MODES[m.group(2)]},nw{m.group(3)}{sfx}>"
     m = re.search(r"aid_attn_short_kernelIDF16b?_?Li(\d+)ELi(\d)", sym)
     if m:
         return f"aid_attn_short<{dt},d{m.group(1)},{MODES[m.group(2)]}>"
     for k in ("aid_gemm_nt_pp_kernel", "aid_gemm_nt_pipe_kernel", "aid_gemm_nt_kernel", "aid_lerp_kv_kernel",
-              "aid_layernorm_kernel"):
+              "aid_layernorm_kernel", "aid_ln_stats_kernel"):
         if k in sym:
-            return f"{k.replace('aid_lerp_kv_kernel', 'aid_lerp_kv').replace('aid_layernorm_kernel', 'aid_layernorm')}<{dt}>"
+            short = {"aid_lerp_kv_kernel": "aid_lerp_kv", "aid_layernorm_kernel": "aid_layernorm", "aid_ln_stats_kernel": "aid_ln_stats"}
+            return f"{short.get(k, k)}<{dt}>"
     return None
 
 
