@@ -863,6 +863,24 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             st.ol[j] = zero16();
         }
     };
+    // Fence between the last MFMAs of a segment and the VALU code that reads the accumulators (finish): the segment
+    // loops end in branches (`is there a ragged tile`), and on a taken path hipcc has left too few wait states between an
+    // MFMA and the first VALU read of its result before (the ragged-tile hazard above).  20 wait states per q block.
+    auto settle = [&](State& st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) asm volatile("" : "+v"(st.o[j][d]));
+            if (XL) asm volatile("" : "+v"(st.ol[j]));
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) asm volatile("" : "+v"(st.o[j][d]));
+            if (XL) asm volatile("" : "+v"(st.ol[j]));
+        }
+    };
     // 1 / (row sum) of a finished state: the sum sits in the ones-row of O^T at the lanes of half 0
     auto inv_l = [&](const State& st, int j) __attribute__((always_inline)) {
         const float lv = XL ? st.ol[j][0] : st.o[j][LBLK][LREG];
@@ -984,13 +1002,18 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 
     if (single) {
         run(st, k_own, v_own, r_own);
+        settle(st);
         finish(res, st, 1.f, false);
     } else if (MODE == AID_MODE_INNER) {
         if (a.fused) run(st, k_own, v_own, r_own);
         run(st, k_mix, v_mix, r_mix);
+        settle(st);
         finish(res, st, 1.f, false);
     } else {
-        if (a.fused) run(st, k_own, v_own, r_own);
+        if (a.fused) {
+            run(st, k_own, v_own, r_own);
+            settle(st);                                     // the snapshot below copies the accumulators on the VALU
+        }
 #pragma unroll
         for (int j = 0; j < QB; ++j)
 #pragma unroll
@@ -998,10 +1021,12 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
         if (cf != 1.f) {                                    // begin side, weight (1 - c)
             State sb = st;
             run(sb, k_beg, v_beg, r_beg);
+            settle(sb);
             finish(res, sb, 1.f - cf, false);
         }
         if (cf != 0.f) {                                    // end side, weight c
             run(st, k_end, v_end, r_end);
+            settle(st);
             finish(res, st, cf, true);
         }
     }
