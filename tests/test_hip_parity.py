@@ -187,6 +187,37 @@ def test_attention_every_ragged_key_count(dtype, d, resident, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("knob,d,expect", [("AID_ATTN_NW=8", 64, "nw8"), ("AID_ATTN_NW=8", 40, "nw8"), ("AID_ATTN_NW=8", 80, "nw8"),
+                                           ("AID_ATTN_PIPE=1", 40, "pipe"), ("AID_ATTN_PIPE=1", 64, "pipe"),
+                                           ("AID_ATTN_QB=2", 40, "qb2"), ("AID_ATTN_QB=1", 40, "nw4"),
+                                           ("AID_ATTN_ORDER=0", 64, "nw4")])
+def test_attention_variants_behind_the_development_knobs(dtype, knob, d, expect, monkeypatch):
+    """The kernel variants that are built but not (or not everywhere) the default — eight-wave workgroups, the
+    software-pipelined loop, 64 rows per wave, the plain XCD order — against the oracle at a shape with several full tiles, a
+    ragged one and riders, so they stay correct while the defaults move (profiles/r02_attn_notes.txt has their timings)."""
+    k_, v_ = knob.split("=")
+    monkeypatch.setenv(k_, v_)
+    n, s, l, h = 5, 300, 330, 2
+    q, k, v, vt = _core_inputs(2 * n, s, l, h, d, dtype, seed=d + len(knob))
+    coef = torch.cat([_coef(n), -torch.ones(n)])
+    seen = set()
+    for mode, fused in MODES:
+        o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused,
+                         coef=None if mode == "plain" else coef.to(DEV), begin=0, end=n - 1,
+                         n_plain=0 if mode == "plain" else n)
+        seen.add(ops.last_attn_variant())
+        q64, k64, v64 = to_np64(q), to_np64(k), to_np64(v)
+        if mode == "plain":
+            ref = O.attn_core(q64, k64, v64, h, d ** -0.5, "plain", False, None)
+        else:
+            ref = np.concatenate([O.attn_core(q64[:n], k64[:n], v64[:n], h, d ** -0.5, mode, fused, coef[:n].numpy()),
+                                  O.attn_core(q64[n:], k64[n:], v64[n:], h, d ** -0.5, "plain", False, None)])
+        err = rel_l2(to_np64(o), ref)
+        assert err < TOL[dtype] and worst(to_np64(o), ref) < WORST[dtype], (knob, mode, fused, ops.last_attn_variant(), err)
+    assert any(expect in nm for nm in seen), (knob, seen)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
 def test_attention_core_sharded_endpoints_accumulate_and_maps(dtype):
     """begin/end != (0, N-1), kv_map, frame_scale, out_scale and accumulate (what the IP processors and
     the frame-sharded multi-GPU layout use)."""
