@@ -3,6 +3,7 @@
 // aid_gemm.hip / aid_attn.hip.  No allocation, no synchronisation, no exceptions.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -52,6 +53,22 @@ struct ProfScope {          // records an event pair around one launch when prof
         if (on) (void)hipEventRecord(g_prof.back().t1, stream);
     }
 };
+
+// ---- tuning knobs (aid_kernels.hpp: enum Tune) -----------------------------------------------------
+const char* const g_tune_names[aid::TUNE_COUNT] = {"GEMM_VARIANT", "GEMM_PP", "GEMM_TRI", "ATTN_NW", "ATTN_QB", "ATTN_PIPE",
+                                                   "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2"};
+struct TuneTable {
+    int v[aid::TUNE_COUNT];
+    TuneTable() {                               // runs once, when the library is loaded
+        for (int i = 0; i < aid::TUNE_COUNT; ++i) {
+            char name[64];
+            snprintf(name, sizeof(name), "AID_%s", g_tune_names[i]);
+            const char* e = getenv(name);
+            v[i] = (e && *e) ? atoi(e) : -1;
+        }
+    }
+};
+TuneTable g_tune;
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -142,9 +159,24 @@ int check_processor(const AidProcessorArgs& a) {
 
 }  // namespace
 
+namespace aid {
+int tune(int id) { return (id >= 0 && id < TUNE_COUNT) ? g_tune.v[id] : -1; }
+}  // namespace aid
+
 extern "C" {
 
 int aid_abi_version(void) { return AID_ABI_VERSION; }
+
+int aid_set_tuning(const char* name, int value) {
+    if (!name) return AID_ERR_ARG;
+    if (!strncmp(name, "AID_", 4)) name += 4;
+    for (int i = 0; i < aid::TUNE_COUNT; ++i)
+        if (!strcmp(name, g_tune_names[i])) {
+            g_tune.v[i] = value < 0 ? -1 : value;
+            return AID_OK;
+        }
+    return AID_ERR_ARG;
+}
 
 const char* aid_strerror(int code) {
     switch (code) {

@@ -1096,10 +1096,10 @@ static int attn_qb(const AidAttnArgs& a);
 // 5 - 19 % and the 77-key cross-attention launches 4 - 8 % (profiles/r02_attn_notes.txt).  Built for d <= 80; development
 // knob AID_ATTN_NW = 4 / 8.
 static int attn_nw(const AidAttnArgs& a) {
-    const char* env = getenv("AID_ATTN_NW");
+    const int knob = tune(TUNE_ATTN_NW);
     if (a.d > 80) return 4;
     if (attn_qb(a) >= 2) return 4;
-    if (env) return atoi(env) == 8 ? 8 : 4;
+    if (knob >= 0) return knob == 8 ? 8 : 4;
     return (a.d == 64 && a.mode == AID_MODE_OUTER && a.l >= 2048) ? 8 : 4;
 }
 
@@ -1107,8 +1107,7 @@ static int attn_nw(const AidAttnArgs& a) {
 // pays only where the kernel still fits two waves per SIMD — d = 40 PLAIN (254 VGPRs, +4 % at S = 4096); every other
 // variant needs > 256 VGPRs, runs one wave per SIMD and loses 25-35 %.  Development knob AID_ATTN_QB = 1 / 2 forces it.
 static int attn_qb(const AidAttnArgs& a) {
-    const char* env = getenv("AID_ATTN_QB");          // read per call: tools/kbench_attn_ab.py flips it inside one process
-    const int force = env ? atoi(env) : 0;
+    const int force = tune(TUNE_ATTN_QB);
     if (a.d != 40 || a.mode != AID_MODE_PLAIN) return 1;         // the other 64-row variants are not built (see above)
     if (force == 1 || force == 2) return force;
     return (a.d == 40 && a.mode == AID_MODE_PLAIN && a.s >= 2048 && a.l >= 1024) ? 2 : 1;
@@ -1121,11 +1120,10 @@ static int attn_qb(const AidAttnArgs& a) {
 // instead of three code copies): three waves per SIMD beat the pipelined two (577 vs 588 us at S = 4096).  Not a default
 // any more; development knob AID_ATTN_PIPE = 0 / 1 forces it for the built variants.
 static bool attn_pipe(const AidAttnArgs& a) {
-    const char* env = getenv("AID_ATTN_PIPE");
+    const int knob = tune(TUNE_ATTN_PIPE);
     const bool built = a.d == 40 || (a.d == 64 && a.mode == AID_MODE_PLAIN);
     if (!built || a.l < 192) return false;
-    if (env) return atoi(env) != 0;
-    return false;
+    return knob > 0;
 }
 
 // Resident key segments: short key sets (text tokens, image tokens) at d <= 80.  A workgroup (4 waves) takes one chunk of the
@@ -1135,9 +1133,9 @@ static bool attn_pipe(const AidAttnArgs& a) {
 // one q block per workgroup: +20 %; profiles/r02_attn_notes.txt).  Development knobs AID_ATTN_RES = 0 / 1, AID_ATTN_RES_CHUNKS.
 constexpr int RES_CHUNKS_MAX = 8;
 static bool attn_res(const AidAttnArgs& a) {
-    const char* env = getenv("AID_ATTN_RES");
+    const int knob = tune(TUNE_ATTN_RES);
     if (a.d > 80 || a.l > RES_KEYS) return false;
-    if (env) return atoi(env) != 0;
+    if (knob >= 0) return knob != 0;
     return a.d == 40;           // measured in the stacks: d = 40 -25 % (inner) / -14 % (plain); d = 64 / 80 within +-5 % of streaming
 }
 
@@ -1147,7 +1145,7 @@ static hipError_t launch_nw(AttnKParams& p, hipStream_t stream) {
     if (D <= 80 && attn_res(p.a)) {
         const int nqb = (p.a.s + 127) / 128;                    // 128-row blocks (4 waves x 32 rows)
         int chunks = nqb / 2 < 1 ? 1 : nqb / 2 > RES_CHUNKS_MAX ? RES_CHUNKS_MAX : nqb / 2;
-        if (const char* env = getenv("AID_ATTN_RES_CHUNKS")) chunks = atoi(env) > 0 ? atoi(env) : chunks;
+        if (tune(TUNE_ATTN_RES_CHUNKS) > 0) chunks = tune(TUNE_ATTN_RES_CHUNKS);
         p.nqb = nqb < chunks ? nqb : chunks;
         p.q_iters = (nqb + p.nqb - 1) / p.nqb;
         return launch_variant<T, D, MODE, 4, 1, false, (D <= 80)>(p, stream);
@@ -1254,8 +1252,7 @@ hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** va
     p.a = a;
     p.nqb = 0;
     p.q_iters = 1;
-    if (const char* env = getenv("AID_ATTN_ORDER"))          // development knob: 0 = plain XCD order for mixed launches
-        if (atoi(env) == 0) p.a.n_plain = 0;
+    if (tune(TUNE_ATTN_ORDER) == 0) p.a.n_plain = 0;         // development knob: plain XCD order for mixed launches
     p.c2 = a.softmax_scale * 1.4426950408889634f;
     hipError_t e = (a.dtype == AID_DTYPE_F16) ? launch_d<f16>(p, stream) : launch_d<bf16>(p, stream);
     if (variant) *variant = attn_variant_name(a);

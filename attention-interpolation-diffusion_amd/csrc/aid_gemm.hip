@@ -27,6 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 namespace aid {
 
 struct TileCoord {
@@ -655,23 +657,81 @@ struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
     }
     // MFMA slot of phase P: acc[0..1][2P .. 2P+1] += B blocks x A blocks of half P; 16 MFMAs on 4 independent
     // accumulators with the phase's four DMAs in between
-    template <int P>
+    template <int P, bool DMA = true, bool PRIO = false>
     __device__ __forceinline__ void half(const T8 (&fb)[2][4], const T8 (&fa)[2][4], int kt, int kb, int nk) {
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ks = i >> 2, in = (i >> 1) & 1, e = i & 1;
             acc[in][2 * P + e] = mfma32(fb[in][ks], fa[e][ks], acc[in][2 * P + e]);
-            if (i == 2 || i == 5 || i == 8 || i == 11) {
+            if (DMA && (i == 2 || i == 5 || i == 8 || i == 11)) {
                 __builtin_amdgcn_sched_barrier(0);
                 issue<P>(kt, kb, nk, (i - 2) / 3);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     static __device__ __forceinline__ void slot() {          // slot boundary: nothing moves across
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- variant: the DMAs are issued in the READ slots -----------------------------------------------------------
+    // A wave in its MFMA slot issues nothing but MFMAs; the half-tiles are requested by the OTHER group's waves, which sit
+    // in their read slot at that time (fragment reads, then four LDS-DMAs, then the waits, then the barrier).  In-order issue
+    // means a `buffer_load ... lds` that finds the address path backed up holds everything queued behind it; here that is a
+    // wave with no MFMA to issue.  Stream per wave:  B(0) A(0) B(1) | A(1) B(2) | A(2) B(3) | ...   (4 DMAs per half pair)
+    //   READ-P0(kt): reads B0 B1 A0 of tile kt, requests A0 A1 of kt + 1 (parity of kt - 1: last read two slots ago),
+    //                retires A1(kt) (newer in the stream: B(kt+1), A(kt+1) -> vmcnt 8)
+    //   READ-P1(kt): reads A1(kt), requests B0 B1 of kt + 2 (parity of kt: read in READ-P0(kt)), retires B(kt+1) and
+    //                A0(kt+1) (newer: A1(kt+1), B(kt+2) -> vmcnt 6)
+    // Every read slot ends with lgkmcnt(0) BEFORE its barrier: a buffer may then be refilled by anybody two slots after
+    // the slot that read it (the second group runs one barrier behind the first).
+    template <int Q>
+    __device__ __forceinline__ void dma_half(int t, int kb) {
+        dma_one<Q>(t & 1, (kb + t) * 64, 0);
+        dma_one<Q>(t & 1, (kb + t) * 64, 1);
+    }
+    template <bool PRIO>
+    __device__ __forceinline__ void mac_rd(int kb, int ke) {
+        const int nk = ke - kb;
+        dma_half<0>(0, kb); dma_half<1>(0, kb); dma_half<2>(0, kb); dma_half<3>(0, kb);
+        if (nk > 1) { dma_half<0>(1, kb); dma_half<1>(1, kb); wait_vmcnt<6>(); }
+        else        wait_vmcnt<2>();
+        slot();
+        if (wr == 1) slot();                // the second group runs one barrier behind
+        T8 fa[2][4], fb[2][4];
+        auto body = [&](int kt, auto more1_t, auto more2_t) __attribute__((always_inline)) {
+            constexpr bool M1 = decltype(more1_t)::value, M2 = decltype(more2_t)::value;   // tile kt + 1 / kt + 2 exists
+            const char* st = smem + (kt & 1) * STG;
+            read_b(fb, st);
+            read_a(fa, st, 0);
+            if (M1) { dma_half<2>(kt + 1, kb); dma_half<3>(kt + 1, kb); }
+            if (M1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            slot();
+            half<0, false, PRIO>(fb, fa, kt, kb, nk);
+            slot();
+            read_a(fa, st, 1);
+            if (M2) { dma_half<0>(kt + 2, kb); dma_half<1>(kt + 2, kb); }
+            if (M2)      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if (M1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            slot();
+            half<1, false, PRIO>(fb, fa, kt, kb, nk);
+            slot();
+        };
+        const std::true_type Y{};
+        const std::false_type N{};
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) body(kt, Y, Y);           // steady state: no branch inside
+        if (kt + 1 < nk) { body(kt, Y, N); ++kt; }
+        if (kt < nk) body(kt, N, N);
+        if (wr == 0) slot();
+        wait_vmcnt<0>();
+        __syncthreads();                    // everyone is done reading the ring
     }
 
     // Precondition: no VMEM operation of this wave outstanding, nobody still reads the LDS.
@@ -709,7 +769,7 @@ struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
 constexpr int PP_SMALL_NS = 4;
 static_assert(Engine<bf16, 128, 128, 64, PP_SMALL_NS, 2, 4>::SMEM <= PingPong<bf16>::SMEM, "small tiles use the big tile's LDS");
 
-template <typename T>
+template <typename T, int PPV>
 __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, const int n_big, const GemmSide sd) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if ((int)blockIdx.x < sd.pad_tiles) {                          // side problems first: their long K loops start at once
@@ -748,7 +808,9 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         e.init(smem_raw);
         e.set_tile(P, A, B, tc.m0, tc.n0);
         e.zero_acc();
-        e.mac(0, P.k / 64);
+        if (PPV == 1)      e.template mac_rd<false>(0, P.k / 64);
+        else if (PPV == 2) e.template mac_rd<true>(0, P.k / 64);
+        else               e.mac(0, P.k / 64);
         e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr,
                      P.ln_stats ? P.ln_stats + 2 * (int64_t)tc.batch * P.stride_stats : nullptr);
     } else {
@@ -859,22 +921,30 @@ static PpPlan plan_pp(GemmGroup& g, int ncu, int nk) {
     return pl;
 }
 
-template <typename T>
-static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl, const GemmSide& sd) {
+template <typename T, int PPV>
+static hipError_t launch_pp_v(GemmGroup& g, hipStream_t stream, const PpPlan& pl, const GemmSide& sd) {
     static PerDevice<bool> attr_set;
     if (pl.tiles <= 0) return hipSuccess;
     if (plan_tiles(g, 256, 256) != pl.tiles) return hipErrorInvalidValue;      // g.tile_start must be in 256 x 256 units
     bool* done = attr_set.slot();
     if (!done) return hipErrorInvalidDevice;
     if (!*done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(aid_gemm_nt_pp_kernel<T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(aid_gemm_nt_pp_kernel<T, PPV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PingPong<T>::SMEM);
         if (e != hipSuccess) return e;
         *done = true;
     }
-    hipLaunchKernelGGL(aid_gemm_nt_pp_kernel<T>, dim3(sd.pad_tiles + pl.n_big + pl.n_small), dim3(512), PingPong<T>::SMEM,
+    hipLaunchKernelGGL((aid_gemm_nt_pp_kernel<T, PPV>), dim3(sd.pad_tiles + pl.n_big + pl.n_small), dim3(512), PingPong<T>::SMEM,
                        stream, g, pl.n_big, sd);
     return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl, const GemmSide& sd) {
+    switch (tune(TUNE_GEMM_PP)) {
+        case 1:  return launch_pp_v<T, 1>(g, stream, pl, sd);
+        case 2:  return launch_pp_v<T, 2>(g, stream, pl, sd);
+        default: return launch_pp_v<T, 0>(g, stream, pl, sd);
+    }
 }
 
 // Two engines serve the k % 64 == 0 shapes; which one a launch gets is decided by a two-line cost model fitted to
@@ -896,7 +966,7 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** var
                                 plan_tiles(g, GBM, GBN), stream, GTHREADS);
     }
     // development knob (tools/gemm_shapes.py): AID_GEMM_VARIANT=7 / 31 forces the lock-step / ping-pong engine
-    static const int force = getenv("AID_GEMM_VARIANT") ? atoi(getenv("AID_GEMM_VARIANT")) : 0;
+    const int force = tune(TUNE_GEMM_VARIANT);
     const int ncu = num_cu();
     if (ncu <= 0) return hipErrorInvalidDevice;
     bool pp = false;

@@ -45,6 +45,24 @@ struct GemmSide {
     int32_t  pad_tiles;                   // tiles rounded up to a multiple of 8 (keeps block -> XCD of the main tiles)
 };
 
+// Development / tuning knobs.  They are NOT read from the environment in the launch path: the table is filled once when
+// the library is loaded (environment variables AID_<NAME>, e.g. AID_ATTN_NW=8) and can be changed at run time through
+// aid_set_tuning() — same-process A/B runs flip a knob between launches.  -1 = unset (the launch heuristics decide).
+enum Tune {
+    TUNE_GEMM_VARIANT = 0,      // 7 = force the lock-step engine, 31 = force the ping-pong engine
+    TUNE_GEMM_PP,               // ping-pong K loop: 0 = DMA issued between the MFMAs, 1 = in the read slot, 2 = 1 + s_setprio, 3 = 0 + s_setprio
+    TUNE_GEMM_TRI,              // 0 = never use the twelve-wave 288 x 256 engine, 1 = force it where the shape allows
+    TUNE_ATTN_NW,               // 4 / 8 waves per workgroup
+    TUNE_ATTN_QB,               // 1 / 2 query blocks per wave (d = 40 PLAIN)
+    TUNE_ATTN_PIPE,             // 0 / 1 software-pipelined loop
+    TUNE_ATTN_RES,              // 0 / 1 resident key segments
+    TUNE_ATTN_RES_CHUNKS,       // > 0: chunks per (frame, head) of the resident variant
+    TUNE_ATTN_ORDER,            // 0 = plain XCD order for mixed launches
+    TUNE_ATTN_V2,               // 0 / 1: the one-wave-per-SIMD d = 64 kernel
+    TUNE_COUNT
+};
+int tune(int id);
+
 // picks the tile shape, fills g.tile_start and launches
 hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const char** variant = nullptr);
 

@@ -272,6 +272,11 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
     return out
 
 
+def set_tuning(name: str, value: int = -1) -> None:
+    """Development knob of the library (``aid_set_tuning``): ``value < 0`` hands the choice back to the launch heuristics."""
+    _lib.check(_lib.load().aid_set_tuning(name.encode(), int(value)), f"aid_set_tuning({name})")
+
+
 def last_attn_variant() -> str:
     return _lib.load().aid_last_attn_variant().decode()
 

@@ -51,3 +51,19 @@ def _blas_threads_match_the_cpu_quota():
             yield
     except ImportError:
         yield
+
+
+@pytest.fixture
+def tuning():
+    """Set development knobs of the library for one test (`aid_set_tuning`); every knob touched goes back to "heuristic"
+    afterwards.  The library reads AID_* environment variables only once, when it is loaded — never on the launch path."""
+    from aid_amd import ops
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        ops.set_tuning(name, value)
+
+    yield set_
+    for name in touched:
+        ops.set_tuning(name, -1)

@@ -167,12 +167,12 @@ def test_attention_core_all_modes(dtype, d, shape):
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
 @pytest.mark.parametrize("d", [40, 64, 80])
 @pytest.mark.parametrize("resident", ["0", "1"], ids=["streaming", "resident"])
-def test_attention_every_ragged_key_count(dtype, d, resident, monkeypatch):
+def test_attention_every_ragged_key_count(dtype, d, resident, tuning):
     """Every number of valid keys in the last (ragged) tile, on the streaming kernel and on the resident-segment
     kernel (which serves l <= 96 by default).  16 < l % 64 <= 32 is the case a branchy ragged tile got wrong on the
     resident kernel: hipcc left too few wait states between the last MFMA of a score block and the first VALU read of it
     on the taken path (keys 22 / 30 of the tile lost their last k-step) — the tile is straight-line now."""
-    monkeypatch.setenv("AID_ATTN_RES", resident)           # the library reads the knob per call
+    tuning("ATTN_RES", int(resident))
     n, s, h = 3, 48, 2
     coef = _coef(n)
     for l in (1, 7, 8, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 77, 80, 88, 95, 96, 97, 120, 128, 160):
@@ -191,12 +191,12 @@ def test_attention_every_ragged_key_count(dtype, d, resident, monkeypatch):
                                            ("AID_ATTN_PIPE=1", 40, "pipe"), ("AID_ATTN_PIPE=1", 64, "pipe"),
                                            ("AID_ATTN_QB=2", 40, "qb2"), ("AID_ATTN_QB=1", 40, "nw4"),
                                            ("AID_ATTN_ORDER=0", 64, "nw4")])
-def test_attention_variants_behind_the_development_knobs(dtype, knob, d, expect, monkeypatch):
+def test_attention_variants_behind_the_development_knobs(dtype, knob, d, expect, tuning):
     """The kernel variants that are built but not (or not everywhere) the default — eight-wave workgroups, the
     software-pipelined loop, 64 rows per wave, the plain XCD order — against the oracle at a shape with several full tiles, a
     ragged one and riders, so they stay correct while the defaults move (profiles/r02_attn_notes.txt has their timings)."""
     k_, v_ = knob.split("=")
-    monkeypatch.setenv(k_, v_)
+    tuning(k_, int(v_))
     n, s, l, h = 5, 300, 330, 2
     q, k, v, vt = _core_inputs(2 * n, s, l, h, d, dtype, seed=d + len(knob))
     coef = torch.cat([_coef(n), -torch.ones(n)])
