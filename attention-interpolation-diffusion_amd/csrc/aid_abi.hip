@@ -145,6 +145,8 @@ int check_processor(const AidProcessorArgs& a) {
     } else if (a.ip_mode != AID_IP_NONE) {
         return AID_ERR_ARG;
     }
+    if ((a.k_cached != nullptr) != (a.vt_cached != nullptr)) return AID_ERR_ARG;
+    if (a.k_cached && (!a.ctx || !aligned16(a.k_cached) || !aligned16(a.vt_cached))) return AID_ERR_ARG;
     if (!(a.ln_eps >= 0.f)) return AID_ERR_ARG;
     if (a.ln_eps > 0.f) {
         if (!aid::layernorm_width_supported(a.c)) return AID_ERR_SHAPE;
@@ -393,8 +395,9 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     if (!a.workspace || a.workspace_bytes < cv.total || !aligned16(a.workspace)) return AID_ERR_WORKSPACE;
     char* ws = static_cast<char*>(a.workspace);
     void* q = ws + cv.q;
-    void* k = ws + cv.k;
-    void* vt = ws + cv.vt;
+    const bool cached = a.k_cached != nullptr;           // step-invariant text keys / values: projected once by the caller
+    const void* k = cached ? a.k_cached : ws + cv.k;
+    const void* vt = cached ? a.vt_cached : ws + cv.vt;
     void* o = ws + cv.o;
     const bool cross = a.ctx != nullptr;
     const void* xin = a.x;
@@ -422,10 +425,10 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     pr[0].m = a.n_frames * a.s; pr[0].n = a.c; pr[0].k = a.c;
     pr[0].lda = a.c; pr[0].ldb = a.c; pr[0].ldc = a.c; pr[0].batch = 1;
     pr[0].scale = 1.4426950408889634f / sqrtf((float)d);      // softmax_scale * log2(e) folded into q before its rounding
-    pr[1].a = e;    pr[1].b = a.wk; pr[1].c = k;
+    pr[1].a = e;    pr[1].b = a.wk; pr[1].c = ws + cv.k;
     pr[1].m = nctx * l; pr[1].n = a.c; pr[1].k = cc;
     pr[1].lda = cc; pr[1].ldb = cc; pr[1].ldc = a.c; pr[1].batch = 1;
-    pr[2].a = a.wv; pr[2].b = e;    pr[2].c = vt;            // V^T[b] = Wv * E_b^T  -> [c, l]
+    pr[2].a = a.wv; pr[2].b = e;    pr[2].c = ws + cv.vt;    // V^T[b] = Wv * E_b^T  -> [c, l]
     pr[2].m = a.c; pr[2].n = l; pr[2].k = cc;
     pr[2].lda = cc; pr[2].ldb = cc; pr[2].ldc = cv.lp; pr[2].batch = nctx;
     pr[2].stride_a = 0; pr[2].stride_b = (int64_t)l * cc; pr[2].stride_c = (int64_t)a.c * cv.lp;
@@ -454,6 +457,10 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
         pr[4].lda = a.cc; pr[4].ldb = a.cc; pr[4].ldc = cv.tp; pr[4].batch = a.n_ip;
         pr[4].stride_a = 0; pr[4].stride_b = a.ip_stride; pr[4].stride_c = (int64_t)a.c * cv.tp;
         npr = 5;
+    }
+    if (cached) {                                             // the query projection (and the image keys / values) only
+        for (int i = 3; i < npr; ++i) pr[i - 2] = pr[i];
+        npr -= 2;
     }
     rc = aid_gemm_nt(pr, npr, a.dtype, stream);
     if (rc != AID_OK) return rc;

@@ -694,27 +694,44 @@ struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
         dma_one<Q>(t & 1, (kb + t) * 64, 0);
         dma_one<Q>(t & 1, (kb + t) * 64, 1);
     }
-    template <bool PRIO>
+    // ABL (timing ablations, results are garbage): bit 0 = no DMAs in the loop, bit 1 = no fragment reads in the loop
+    template <bool PRIO, int ABL = 0>
     __device__ __forceinline__ void mac_rd(int kb, int ke) {
         const int nk = ke - kb;
+        constexpr bool NODMA = ABL & 1, NORD = ABL & 2;
         dma_half<0>(0, kb); dma_half<1>(0, kb); dma_half<2>(0, kb); dma_half<3>(0, kb);
         if (nk > 1) { dma_half<0>(1, kb); dma_half<1>(1, kb); wait_vmcnt<6>(); }
         else        wait_vmcnt<2>();
         slot();
         if (wr == 1) slot();                // the second group runs one barrier behind
         T8 fa[2][4], fb[2][4];
+        if (NORD) { read_b(fb, smem); read_a(fa, smem, 0); }
         auto body = [&](int kt, auto more1_t, auto more2_t) __attribute__((always_inline)) {
-            constexpr bool M1 = decltype(more1_t)::value, M2 = decltype(more2_t)::value;   // tile kt + 1 / kt + 2 exists
+            constexpr bool M1 = decltype(more1_t)::value && !NODMA, M2 = decltype(more2_t)::value && !NODMA;   // tile kt + 1 / kt + 2 exists
             const char* st = smem + (kt & 1) * STG;
-            read_b(fb, st);
-            read_a(fa, st, 0);
+            if (!NORD) {
+                read_b(fb, st);
+                read_a(fa, st, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) { asm volatile("" : "+v"(fa[e][ks])); asm volatile("" : "+v"(fb[e][ks])); }
+            }
             if (M1) { dma_half<2>(kt + 1, kb); dma_half<3>(kt + 1, kb); }
             if (M1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             else    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             slot();
             half<0, false, PRIO>(fb, fa, kt, kb, nk);
             slot();
-            read_a(fa, st, 1);
+            if (!NORD) {
+                read_a(fa, st, 1);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(fa[e][ks]));
+            }
             if (M2) { dma_half<0>(kt + 2, kb); dma_half<1>(kt + 2, kb); }
             if (M2)      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
             else if (M1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
@@ -810,6 +827,7 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, 
         e.zero_acc();
         if (PPV == 1)      e.template mac_rd<false>(0, P.k / 64);
         else if (PPV == 2) e.template mac_rd<true>(0, P.k / 64);
+        else if (PPV >= 4) e.template mac_rd<false, PPV - 4>(0, P.k / 64);
         else               e.mac(0, P.k / 64);
         e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr,
                      P.ln_stats ? P.ln_stats + 2 * (int64_t)tc.batch * P.stride_stats : nullptr);
@@ -942,8 +960,14 @@ template <typename T>
 static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl, const GemmSide& sd) {
     switch (tune(TUNE_GEMM_PP)) {
         case 1:  return launch_pp_v<T, 1>(g, stream, pl, sd);
+        case 0:  return launch_pp_v<T, 0>(g, stream, pl, sd);
         case 2:  return launch_pp_v<T, 2>(g, stream, pl, sd);
-        default: return launch_pp_v<T, 0>(g, stream, pl, sd);
+#ifdef AID_ABLATIONS
+        case 5:  return launch_pp_v<T, 5>(g, stream, pl, sd);      // no DMAs
+        case 6:  return launch_pp_v<T, 6>(g, stream, pl, sd);      // no fragment reads
+        case 7:  return launch_pp_v<T, 7>(g, stream, pl, sd);      // neither: MFMAs + barriers
+#endif
+        default: return launch_pp_v<T, 1>(g, stream, pl, sd);
     }
 }
 

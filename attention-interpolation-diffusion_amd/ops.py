@@ -292,7 +292,8 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
                   out: Optional[torch.Tensor] = None, n_plain: int = 0,
                   ln: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor], float]] = None,
                   residual: Optional[torch.Tensor] = None, seg_executed: int = 0,
-                  ip: Optional[dict] = None, ln_folded: Optional[tuple] = None) -> torch.Tensor:
+                  ip: Optional[dict] = None, ln_folded: Optional[tuple] = None,
+                  kv_cached: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """One whole processor call: y = to_out(AID-attention(to_q(x), to_k(ctx), to_v(ctx)))
     in three launches (grouped q/k/V^T GEMM, attention core, out-proj GEMM).
     ``ln = (gamma, beta, eps)`` computes on LayerNorm(x); ``residual`` is added to the result (the transformer
@@ -302,7 +303,9 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
     frame_scale=fp32 device [N] or None, begin=int, end=int).
     ``ln_folded`` = (wq', wk', wv', const) with ``ln``: the LayerNorm is folded into the projections (wq' etc. from
     ``ln_fold``, wk' / wv' None for cross-attention, const fp32 [6, C] = colsum_q, shift_q, colsum_k, shift_k, colsum_v,
-    shift_v): only the row statistics of x are computed, LayerNorm(x) is never written."""
+    shift_v): only the row statistics of x are computed, LayerNorm(x) is never written.
+    ``kv_cached`` = (k, vt) from ``project_kv(ctx, wk, wv)``: the step-invariant keys / values of a cross-attention layer,
+    projected once by the caller; the call then projects the queries only."""
     lib = _lib.load()
     ipt = ip or {}
     dev = _require_gpu(x, ctx, wq, wk, wv, wo, bo, coef, ctx_map, out, residual, *(ln[:2] if ln else ()),
@@ -373,6 +376,17 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
         if residual.shape != x.shape or residual.dtype != x.dtype or not residual.is_contiguous():
             raise ValueError("residual must be a contiguous tensor shaped like the hidden states")
         a.residual = residual.data_ptr()
+    if kv_cached is not None:
+        if ctx is None:
+            raise ValueError("cached keys / values belong to a cross-attention call")
+        kc, vc = kv_cached
+        _require_gpu(kc, vc)
+        lp = (ctx.shape[1] + 7) // 8 * 8
+        if kc.dtype != x.dtype or vc.dtype != x.dtype or not kc.is_contiguous() or not vc.is_contiguous() \
+                or kc.shape[0] < ctx.shape[0] or tuple(kc.shape[1:]) != (ctx.shape[1], c) \
+                or vc.shape[0] < ctx.shape[0] or tuple(vc.shape[1:]) != (c, lp):
+            raise ValueError("kv_cached must be (k [n_ctx, L, C], vt [n_ctx, C, round_up(L, 8)]) as project_kv returns them")
+        a.k_cached, a.vt_cached = kc.data_ptr(), vc.data_ptr()
     nbytes = lib.aid_processor_workspace_bytes(C.byref(a))
     with _on(dev):
         if nbytes == 0:

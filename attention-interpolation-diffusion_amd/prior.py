@@ -27,17 +27,15 @@ def clip_distance(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def update_alpha_beta(xs: Sequence[float], ds: Sequence[float]) -> Tuple[float, float]:
-    """Fit Beta(alpha, beta) so that its CDF at ``xs`` follows the normalised cumulative distances (prior.py:35-56)."""
+    """Beta(alpha, beta) whose CDF, sampled at the explored coefficients ``xs``, follows the share of the total perceptual
+    distance covered up to each of them (prior.py:35-56): least squares from (1, 1), both parameters kept positive."""
     total = sum(ds)
-    uniform_points = np.cumsum([0] + [d / total for d in ds])
-    xs = np.asarray(xs)
-    uniform_points = np.asarray(uniform_points)
-
-    def beta_cdf(x, alpha, beta_param):
-        return beta_distribution.cdf(x, alpha, beta_param)
-
-    params, _ = curve_fit(beta_cdf, xs, uniform_points, p0=[1.0, 1.0], bounds=([1e-6, 1e-6], [np.inf, np.inf]))
-    return params[0], params[1]
+    # accumulated in the precision of the distances themselves (fp32 CLIP distances in the reference's runs): the fitted
+    # parameters move at the 1e-7 level with the rounding of these targets, and the goldens pin them
+    share = np.asarray(np.cumsum([0] + [d / total for d in ds]))
+    fit, _ = curve_fit(beta_distribution.cdf, np.asarray(xs), share, p0=[1.0, 1.0],
+                       bounds=([1e-6, 1e-6], [np.inf, np.inf]))
+    return fit[0], fit[1]
 
 
 def next_point(xs: Sequence[float], ds: Sequence[float], alpha: float, beta_param: float,
@@ -57,66 +55,130 @@ def next_point(xs: Sequence[float], ds: Sequence[float], alpha: float, beta_para
 
 
 def extract_uniform_points(ds: Sequence[float], interpolation_size: int) -> List[int]:
-    """Greedy pick of frames at equal cumulative distance (prior.py:201-210)."""
-    expected = sum(ds) / (interpolation_size - 1)
-    current, out = 0, [0]
-    for idx, d in enumerate(ds):
-        current += d
-        if current >= expected:
-            out.append(idx)
-            current = 0
-    return out
+    """Frames at (roughly) equal arc length: walk the gaps and emit the gap index every time the distance accumulated since
+    the last emitted frame reaches total / (size - 1) (prior.py:201-210; the reference emits the index of the GAP, quirk kept)."""
+    quota = sum(ds) / (interpolation_size - 1)
+    picks, walked = [0], 0
+    for gap, length in enumerate(ds):
+        walked += length
+        if walked >= quota:
+            picks.append(gap)
+            walked = 0
+    return picks
 
 
-def is_path_possible(D, n, m, weights, W):
-    """prior.py:256-297: is there a path 0 -> m-1 over n nodes whose edge weights lie in a window of width D?"""
-    for w_min in W:
-        w_max = w_min + D
-        if w_max > W[-1]:
-            break
-        dp = [[None] * (n + 1) for _ in range(m)]
-        dp[0][1] = (float("-inf"), float("inf"), [0])
-        for l in range(1, n):
-            for i in range(m):
-                if dp[i][l] is None:
-                    continue
-                max_w, min_w, path = dp[i][l]
-                for j in range(i + 1, m):
-                    w = weights[i][j]
-                    if w != -1 and w_min <= w <= w_max:
-                        new_max, new_min = max(max_w, w), min(min_w, w)
-                        if new_max - new_min <= D:
-                            cur = dp[j][l + 1]
-                            if cur is None or new_max - new_min < cur[0] - cur[1]:
-                                dp[j][l + 1] = (new_max, new_min, path + [j])
-        if dp[m - 1][n] is not None:
-            return dp[m - 1][n][2]
-    return None
+# ---- smoothest path through the explored frames (prior.py:212-297) ----------------------------------------------------------
+# Task: among the increasing node sequences 0 = p_0 < ... < p_{n-1} = m - 1 pick one whose edge weights w[p_k][p_{k+1}] fit
+# into the narrowest window.  The reference bisects the window width D to 1e-6 and, per trial D, slides a window
+# [w_min, w_min + D] over the sorted distinct weights, running a greedy label DP per window.  Formulation here:
+#   1. the EXACT threshold D* = min over windows of distinct weights [W[lo], W[hi]] that admit an n-node path, by two pointers
+#      over W (feasibility is monotone in both ends) with a boolean reachability product per check;
+#   2. the width the reference's bisection ENDS on is a function of D* alone (its predicate is  D >= D*), so the scalar
+#      iteration is replayed on that predicate without any path search;
+#   3. one label pass in the first window that fits that width, level-synchronous and vectorised over the predecessors, with
+#      parent pointers instead of stored paths.  Labels and tie-breaks are the reference's (keep, per (node, length), the
+#      partial path of smallest spread; among equals the smallest predecessor index), so the picked path is identical —
+#      pinned by tests/golden/prior_goldens.npz.
+def _edges_in(weights: np.ndarray, lo: float, hi: float) -> np.ndarray:
+    """Upper-triangular mask of the existing edges whose weight lies in [lo, hi]."""
+    m = weights.shape[0]
+    return np.triu(np.ones((m, m), dtype=bool), 1) & (weights != -1) & (weights >= lo) & (weights <= hi)
+
+
+def _reachable(mask: np.ndarray, n: int) -> bool:
+    """Is node m - 1 reachable from node 0 in exactly n - 1 steps over the edges of ``mask``?"""
+    front = np.zeros(mask.shape[0], dtype=bool)
+    front[0] = True
+    for _ in range(n - 1):
+        front = (front.astype(np.int64) @ mask.astype(np.int64)) > 0
+        if not front.any():
+            return False
+    return bool(front[-1])
+
+
+def _exact_spread(n: int, weights: np.ndarray, W: np.ndarray) -> Optional[float]:
+    """D*: the smallest W[hi] - W[lo] such that the edges with weights in [W[lo], W[hi]] carry an n-node path."""
+    best, hi = None, 0
+    for lo in range(len(W)):
+        hi = max(hi, lo)
+        while hi < len(W) and not _reachable(_edges_in(weights, W[lo], W[hi]), n):
+            hi += 1
+        if hi == len(W):
+            break                          # no window starting at or after W[lo] works any more
+        width = float(W[hi] - W[lo])
+        if best is None or width < best:
+            best = width
+    return best
+
+
+def _label_pass(n: int, weights: np.ndarray, mask: np.ndarray, width: float) -> Optional[List[int]]:
+    """One sweep of (max, min) labels over path lengths 1 .. n inside one window; returns the path to node m - 1."""
+    m = weights.shape[0]
+    top = np.full((n + 1, m), np.nan)            # label of the kept partial path ending in node j with l nodes
+    low = np.full((n + 1, m), np.nan)
+    parent = np.full((n + 1, m), -1, dtype=np.int64)
+    alive = np.zeros((n + 1, m), dtype=bool)
+    top[1, 0], low[1, 0], alive[1, 0] = -np.inf, np.inf, True
+    for l in range(1, n):
+        src = np.flatnonzero(alive[l])
+        if src.size == 0:
+            return None
+        for j in range(1, m):
+            cand = src[(src < j) & mask[src, j]]
+            if cand.size == 0:
+                continue
+            w = weights[cand, j]
+            hi_, lo_ = np.maximum(top[l, cand], w), np.minimum(low[l, cand], w)
+            spread = hi_ - lo_
+            ok = spread <= width
+            if not ok.any():
+                continue
+            k = int(np.argmin(np.where(ok, spread, np.inf)))          # first minimum = smallest predecessor index
+            top[l + 1, j], low[l + 1, j], parent[l + 1, j], alive[l + 1, j] = hi_[k], lo_[k], cand[k], True
+    if not alive[n, m - 1]:
+        return None
+    path, node = [m - 1], m - 1
+    for l in range(n, 1, -1):
+        node = int(parent[l, node])
+        path.append(node)
+    return path[::-1]
 
 
 def find_minimal_spread_and_path(n: int, m: int, weights) -> Tuple[Optional[float], Optional[List[int]]]:
-    """Bisection on the spread (max - min edge weight) of an n-node path through the m explored frames (prior.py:223-254)."""
-    W = sorted({weights[i][j] for i in range(m - 1) for j in range(i + 1, m) if weights[i][j] != -1})
-    low, high = 0.0, W[-1] - W[0]
-    best_d, best_path = None, None
+    """(window width, node path) of the smoothest n-node path 0 -> m - 1 through the explored frames; the path the
+    reference's bisection + window scan returns (prior.py:223-297), found as described above."""
+    weights = np.asarray(weights, dtype=np.float64)
+    iu = np.triu_indices(m, 1)
+    present = weights[iu]
+    W = np.unique(present[present != -1])
+    d_star = _exact_spread(n, weights, W)
+    # the reference's scalar bisection, replayed on its predicate "a window of width D admits a path" == (D >= D*)
+    low, high, width = 0.0, float(W[-1] - W[0]), None
     while high - low > 1e-6:
         D = (low + high) / 2
-        result = is_path_possible(D, n, m, weights, W)
-        if result is not None:
-            high, best_d, best_path = D, D, result
+        if d_star is not None and D >= d_star:
+            high, width = D, D
         else:
             low = D
-    return best_d, best_path
+    if width is None:
+        return None, None
+    for w_lo in W:                                   # first window of that width (it must end inside the weight range)
+        if w_lo + width > W[-1]:
+            break
+        path = _label_pass(n, weights, _edges_in(weights, w_lo, w_lo + width), width)
+        if path is not None:
+            return width, path
+    return None, None
 
 
 def extract_uniform_points_plus(features: Sequence[torch.Tensor], interpolation_size: int,
                                 distance: Callable = clip_distance) -> Optional[List[int]]:
     """Smoothest path of ``interpolation_size`` frames through the explored ones (prior.py:212-221)."""
     m = len(features)
-    weights = -1 * np.ones((m, m))
-    for i in range(m):
-        for j in range(i + 1, m):
-            weights[i][j] = distance(features[i], features[j])
+    weights = np.full((m, m), -1.0)
+    for a in range(m - 1):
+        for b in range(a + 1, m):
+            weights[a, b] = float(distance(features[a], features[b]))
     return find_minimal_spread_and_path(interpolation_size, m, weights)[1]
 
 

@@ -131,12 +131,13 @@ class InterpolatedAttnProcessor(nn.Module):
                                f"tensor b ({batch}) at non-singleton dimension 0")
         key = (device, dtype, coef.numel(), self.plain_tail)
         ent = self._coef_dev.get(key)
+        ver = _version_of(coef)                       # None: no version counter (inference-mode tensor) -> compare values
         if ent is None:
             vals = _coef_values(coef, dtype, self.plain_tail)
-            ent = [torch.tensor(vals, dtype=torch.float32).to(device), vals, coef._version]
+            ent = [torch.tensor(vals, dtype=torch.float32).to(device), vals, ver]
             self._coef_dev[key] = ent
-        elif ent[2] != coef._version:                 # the tensor was mutated in place (proc.coef[1] = t)
-            _rewrite(ent, _coef_values(coef, dtype, self.plain_tail), coef._version)
+        elif ver is None or ent[2] != ver:            # the tensor was (or may have been) mutated in place (proc.coef[1] = t)
+            _rewrite(ent, _coef_values(coef, dtype, self.plain_tail), ver)
         return ent[0], ent[1]
 
     def _refresh_coef_buffers(self) -> None:
@@ -144,7 +145,16 @@ class InterpolatedAttnProcessor(nn.Module):
         coef = self._coef
         for (device, dtype, n, tail), ent in self._coef_dev.items():
             if n == coef.numel():
-                _rewrite(ent, _coef_values(coef, dtype, tail), coef._version)
+                _rewrite(ent, _coef_values(coef, dtype, tail), _version_of(coef))
+
+
+def _version_of(t: torch.Tensor) -> Optional[int]:
+    """In-place edit counter of a tensor, or None where it cannot be read (tensors created under torch.inference_mode()
+    raise on ``_version``): callers then fall back to comparing values (the small ``coef``) or to the address alone."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
 
 
 def _coef_values(coef: torch.Tensor, dtype: torch.dtype, plain_tail: int) -> Tuple[float, ...]:
@@ -253,7 +263,9 @@ def _ln_folded(attn, norm, cross: bool):
     if c % 64 or (not cross and (wk.shape[1] != c or wv.shape[1] != c)):
         return None
     srcs = (wq, norm.weight, norm.bias) if cross else (wq, wk, wv, norm.weight, norm.bias)
-    key = (cross,) + tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs)
+    # (an inference-mode weight has no version counter: its address alone is the key, and graphs captured with folded
+    #  weights must be re-captured after any weight edit — the rebuilt tensors live at new addresses)
+    key = (cross,) + tuple((t.data_ptr(), _version_of(t)) if t is not None else None for t in srcs)
     ent = _FOLD_CACHE.get(attn)
     if ent is None or ent[0] != key:
         const = torch.zeros(6, wq.shape[0], dtype=torch.float32, device=wq.device)
@@ -267,6 +279,54 @@ def _ln_folded(attn, norm, cross: bool):
     return ent[1]
 
 
+# Step-invariant text keys / values (VERDICT r2 missing #5).  The reference hands the SAME prompt_embeds tensor to every
+# denoising step (pipeline_interpolated_sd.py:1859-1867), so K = to_k(ctx) and V^T = Wv ctx^T of a cross-attention layer
+# are the same numbers in all 50 steps; the reference recomputes them 50 times.  Here they are projected once per
+# (attention module, context tensor, frame -> context map, to_k / to_v weights) and handed to every later call
+# (AidProcessorArgs.k_cached / vt_cached): the grouped launch of a cross-attention call then holds the query projection alone.
+# An entry is keyed by (data_ptr, _version) of the context tensor the CALLER passed and of the two weights — an in-place edit
+# bumps _version and misses — and it disappears when that context tensor is garbage-collected (weakref), so a recycled
+# address can never hit.  Tensors whose version counter cannot be read (inference mode) are not cached.
+# Captured hipGraphs hold the cached buffers' addresses: they stay valid as long as the context tensor they were captured
+# with is alive; re-capture after replacing weights.  ``TEXT_KV_CACHE = False`` switches the cache off.
+TEXT_KV_CACHE = True
+_KV_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _vkey(t: torch.Tensor):
+    v = _version_of(t)                    # inference-mode tensor: in-place edits cannot be detected -> not cached
+    return None if v is None else (t.data_ptr(), v)
+
+
+def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tensor):
+    """(k [n_ctx, L, C], vt [n_ctx, C, Lp]) of the distinct contexts ``ctx`` derived from the caller's tensor ``ehs``
+    (``idx`` = frame -> context map or None), from the cache or projected now; None where caching does not apply."""
+    if not TEXT_KV_CACHE or ehs is None or not torch.is_tensor(ehs):
+        return None
+    ks = (_vkey(ehs), _vkey(wk), _vkey(wv))
+    if None in ks:
+        return None
+    key = ks + (tuple(ehs.shape), ehs.dtype, tuple(idx) if idx is not None else None)
+    try:
+        per = _KV_CACHE.get(attn)
+        if per is None:
+            per = {}
+            _KV_CACHE[attn] = per
+    except TypeError:                     # an attention object that cannot be weakly referenced
+        return None
+    hit = per.get(key)
+    if hit is None:
+        k, vt = ops.project_kv(ctx, wk, wv)
+        for old in [kk for kk in per if kk[0][0] == key[0][0] and kk[3:] == key[3:]]:
+            per.pop(old, None)            # the same tensor at an older version (or with replaced weights)
+
+        def _drop(_ref, per=per, key=key):
+            per.pop(key, None)
+        hit = (k, vt, weakref.ref(ehs, _drop))
+        per[key] = hit
+    return hit[0], hit[1]
+
+
 def _plain_sublayer_ok(attn, hidden_states) -> bool:
     """The one-call form  h + attn(norm(h))  covers the transformer-block attention of SD / SDXL: 3-D input and none of
     the Attention extras (spatial / group norm, own residual connection, output rescale, cross-attention norm)."""
@@ -278,6 +338,7 @@ def _plain_sublayer_ok(attn, hidden_states) -> bool:
 def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidden_states,
               attention_mask, temb, mode: str, ctx_index=None, ln=None, add_to=None, ln_folded=None):
     residual, x, ctx, shape4 = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+    ehs = ctx                                         # the tensor the caller holds on to across steps (cache key)
     wq, wk, wv, wo, bo = _weights(attn)
     coef = vals = None
     if mode != "plain":
@@ -317,7 +378,8 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
     y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode, fused=fused, coef=coef,
                           begin=begin, end=end, ctx_map=ctx_map,
                           n_plain=proc.plain_tail if mode != "plain" else 0, ln=ln, residual=add_to, ln_folded=ln_folded,
-                          seg_executed=ops.executed_segments(mode, fused, vals, x.shape[0], idx, begin, end))
+                          seg_executed=ops.executed_segments(mode, fused, vals, x.shape[0], idx, begin, end),
+                          kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv) if ctx is not None else None)
     return _epilogue(attn, y, residual, shape4)
 
 
@@ -336,26 +398,29 @@ class HipAttnProcessor:
             return hidden_states + self(attn, norm(hidden_states), encoder_hidden_states, ctx_index=ctx_index)
         x = hidden_states.contiguous()
         wq, wk, wv, wo, bo = _weights(attn)
-        ctx, ctx_map = encoder_hidden_states, None
+        ctx, ctx_map, idx = encoder_hidden_states, None, None
         ctx_index = self.ctx_index if ctx_index is None else ctx_index
         if ctx is not None and ctx_index is not None:
-            ctx, ctx_map, _ = _shared_context(self._ctx_cache, ctx_index, ctx, x.shape[0])
+            ctx, ctx_map, idx = _shared_context(self._ctx_cache, ctx_index, ctx, x.shape[0])
         elif ctx is not None:
             ctx = ctx.contiguous()
         return ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map,
-                                 ln=_ln_of(norm), residual=x, ln_folded=_ln_folded(attn, norm, ctx is not None))
+                                 ln=_ln_of(norm), residual=x, ln_folded=_ln_folded(attn, norm, ctx is not None),
+                                 kv_cached=_text_kv(attn, encoder_hidden_states, ctx, idx, wk, wv) if ctx is not None else None)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  *args, ctx_index=None, **kwargs):
         residual, x, ctx, shape4 = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+        ehs = ctx
         wq, wk, wv, wo, bo = _weights(attn)
-        ctx_map = None
+        ctx_map = idx = None
         ctx_index = self.ctx_index if ctx_index is None else ctx_index
         if ctx is not None and ctx_index is not None:
-            ctx, ctx_map, _ = _shared_context(self._ctx_cache, ctx_index, ctx, x.shape[0])
+            ctx, ctx_map, idx = _shared_context(self._ctx_cache, ctx_index, ctx, x.shape[0])
         elif ctx is not None:
             ctx = ctx.contiguous()
-        y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map)
+        y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map,
+                              kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv) if ctx is not None else None)
         return _epilogue(attn, y, residual, shape4)
 
 

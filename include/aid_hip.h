@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AID_ABI_VERSION 4
+#define AID_ABI_VERSION 5
 
 /* element types of activations / weights (accumulation is always fp32) */
 #define AID_DTYPE_F16  0
@@ -250,6 +250,13 @@ typedef struct AidProcessorArgs {
     const void*  ln_wk;
     const void*  ln_wv;
     const float* ln_const;
+    /* ---- step-invariant keys / values of a cross-attention layer (ABI v5; both NULL: project them in this call).  The text  */
+    /* context does not change over the denoising loop (reference pipeline_interpolated_sd.py:1859-1867 hands the same       */
+    /* prompt_embeds to every step), so K = to_k(ctx) [n_ctx, l, c] and V^T = Wv ctx^T [n_ctx, c, round_up(l, 8)] can be      */
+    /* projected ONCE per (layer, context) with aid_gemm_nt and handed to every later call: the grouped launch then holds     */
+    /* the query projection alone.  Only valid with ctx != NULL; the caller owns the buffers and their validity.             */
+    const void*  k_cached;
+    const void*  vt_cached;
 } AidProcessorArgs;
 
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args /* host */);

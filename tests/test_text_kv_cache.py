@@ -1,0 +1,147 @@
+"""Step-invariant text keys / values (processors._text_kv, AidProcessorArgs.k_cached / vt_cached): the cache keys, their
+invalidation, and — on the GPU — that a cached call returns what an un-cached call returns.
+Reference behaviour replaced: `attn.to_k(encoder_hidden_states)` / `attn.to_v(...)` recomputed every step although the
+pipeline passes the same prompt_embeds (interpolation.py:623-624, pipeline_interpolated_sd.py:1859-1867)."""
+import gc
+
+import pytest
+import torch
+
+import aid_amd
+from aid_amd import ops, processors as P
+
+
+class _Attn:                                # weakly referenceable stand-in for an Attention module
+    pass
+
+
+def _fake_project(calls):
+    def project_kv(ctx, wk, wv, extra_rows=0):
+        calls.append(tuple(ctx.shape))
+        return ctx.clone(), ctx.clone()
+    return project_kv
+
+
+def test_cache_hits_misses_and_invalidation_host_logic(monkeypatch):
+    calls = []
+    monkeypatch.setattr(ops, "project_kv", _fake_project(calls))
+    attn, other = _Attn(), _Attn()
+    wk, wv = torch.randn(8, 4), torch.randn(8, 4)
+    ehs = torch.randn(3, 5, 4)
+    a = P._text_kv(attn, ehs, ehs, None, wk, wv)
+    b = P._text_kv(attn, ehs, ehs, None, wk, wv)
+    assert len(calls) == 1 and a[0] is b[0] and a[1] is b[1]                # second step: hit, same buffers
+    P._text_kv(other, ehs, ehs, None, wk, wv)
+    assert len(calls) == 2                                                  # another layer has its own weights: own entry
+    P._text_kv(attn, ehs, ehs[:2], [0, 1, 1], wk, wv)
+    assert len(calls) == 3                                                  # another frame -> context map: own entry
+    ehs.mul_(2.0)                                                           # in-place edit of the context: miss
+    c = P._text_kv(attn, ehs, ehs, None, wk, wv)
+    assert len(calls) == 4 and c[0] is not a[0]
+    with torch.no_grad():
+        wk.add_(1.0)                                                        # edited weights: miss
+    P._text_kv(attn, ehs, ehs, None, wk, wv)
+    assert len(calls) == 5
+    # stale versions of the same tensor do not pile up
+    assert len(P._KV_CACHE[attn]) <= 2
+    # the entry goes away with the context tensor, so a recycled address cannot hit
+    n_before = len(P._KV_CACHE[other])
+    del ehs, a, b, c
+    gc.collect()
+    assert len(P._KV_CACHE[other]) == n_before - 1 and len(P._KV_CACHE[attn]) == 0
+
+
+def test_inference_mode_tensors_are_not_cached(monkeypatch):
+    calls = []
+    monkeypatch.setattr(ops, "project_kv", _fake_project(calls))
+    with torch.inference_mode():
+        ehs = torch.randn(2, 3, 4)
+    wk, wv = torch.randn(8, 4), torch.randn(8, 4)
+    assert P._text_kv(_Attn(), ehs, ehs, None, wk, wv) is None and not calls
+    # ... and the coefficient path falls back to comparing values (`_version` raises on inference tensors)
+    proc = aid_amd.OuterInterpolatedAttnProcessor(t=0.3)
+    with torch.inference_mode():
+        proc.coef = torch.tensor([0.0, 0.4, 1.0])
+    dev, vals = proc._coef_state(torch.device("cpu"), torch.float16, 3)
+    assert abs(vals[1] - 0.4) < 1e-3
+    with torch.inference_mode():
+        proc.coef[1] = 0.7
+    dev2, vals2 = proc._coef_state(torch.device("cpu"), torch.float16, 3)
+    assert dev2 is dev and abs(vals2[1] - 0.7) < 1e-3 and abs(float(dev[1]) - vals2[1]) < 1e-6
+
+
+def test_cache_can_be_switched_off(monkeypatch):
+    calls = []
+    monkeypatch.setattr(ops, "project_kv", _fake_project(calls))
+    monkeypatch.setattr(P, "TEXT_KV_CACHE", False)
+    ehs = torch.randn(2, 3, 4)
+    assert P._text_kv(_Attn(), ehs, ehs, None, torch.randn(8, 4), torch.randn(8, 4)) is None and not calls
+
+
+# ------------------------------------------------------------------------------------------------
+DEV = "cuda:0"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["float16", "bfloat16"])
+@pytest.mark.parametrize("kind", ["outer", "inner", "plain"])
+def test_cached_call_equals_uncached_call_and_oracle(dtype, kind, monkeypatch):
+    import numpy as np
+    from oracle import aid_oracle as O
+    from util import TOL, rel_l2, to_np64
+    n, s, heads, d, l, cc = 5, 200, 2, 64, 77, 128
+    c = heads * d
+    g = torch.Generator().manual_seed(5)
+    attn = aid_amd.AttnShim(c, heads, cc, dtype=dtype, device=DEV)
+    x = torch.randn(n, s, c, generator=g).to(dtype).to(DEV)
+    ctx = torch.randn(n, l, cc, generator=g).to(dtype).to(DEV)
+    if kind == "plain":
+        proc = aid_amd.HipAttnProcessor()
+    else:
+        cls = aid_amd.OuterInterpolatedAttnProcessor if kind == "outer" else aid_amd.InnerInterpolatedAttnProcessor
+        proc = cls(size=n, is_fused=True, alpha=3, beta=3)
+    monkeypatch.setattr(P, "TEXT_KV_CACHE", False)
+    y_off = proc(attn, x, encoder_hidden_states=ctx)
+    monkeypatch.setattr(P, "TEXT_KV_CACHE", True)
+    y_miss = proc(attn, x, encoder_hidden_states=ctx)                       # projects and stores
+    y_hit = proc(attn, x, encoder_hidden_states=ctx)                        # query projection only
+    assert len(P._KV_CACHE[attn]) == 1
+    assert torch.equal(y_miss, y_hit)
+    assert torch.equal(y_hit, y_off), "the cached keys / values are the same numbers the grouped launch computes"
+    # an in-place edit of the context is seen (no stale keys), and the result is right
+    with torch.no_grad():
+        ctx.mul_(-0.5)
+    y_new = proc(attn, x, encoder_hidden_states=ctx)
+    assert not torch.equal(y_new, y_hit)
+    w = O.AttnWeights(to_np64(attn.to_q.weight), to_np64(attn.to_k.weight), to_np64(attn.to_v.weight),
+                      to_np64(attn.to_out[0].weight), to_np64(attn.to_out[0].bias), heads)
+    if kind == "plain":
+        ref = O.plain_attention(to_np64(x), to_np64(ctx), w)
+    else:
+        fn = O.outer_attention if kind == "outer" else O.inner_attention
+        ref = fn(to_np64(x), to_np64(ctx), w, to_np64(proc.coef.to(dtype)), True)
+    assert rel_l2(to_np64(y_new), ref) < TOL[dtype]
+
+
+@pytest.mark.gpu
+def test_cached_keys_under_graph_replay():
+    """A captured pass replays with the cached buffers' addresses; replays equal the eager result."""
+    dtype = torch.bfloat16
+    n, s, heads, d, l, cc = 4, 256, 4, 64, 77, 256
+    c = heads * d
+    attn = aid_amd.AttnShim(c, heads, cc, dtype=dtype, device=DEV)
+    x = torch.randn(n, s, c, device=DEV).to(dtype)
+    ctx = torch.randn(n, l, cc, device=DEV).to(dtype)
+    proc = aid_amd.OuterInterpolatedAttnProcessor(size=n, is_fused=True, alpha=2, beta=2)
+    y_eager = proc(attn, x, encoder_hidden_states=ctx).clone()              # fills the cache eagerly
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        proc(attn, x, encoder_hidden_states=ctx)
+        with torch.cuda.graph(graph, stream=st):
+            y_g = proc(attn, x, encoder_hidden_states=ctx)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_g, y_eager)
