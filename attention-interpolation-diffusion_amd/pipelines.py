@@ -132,11 +132,16 @@ class StackDenoiser(nn.Module):
     def forward(self, sample, timestep=None, encoder_hidden_states=None, added_cond_kwargs=None, return_dict=False, **kw):
         n = sample.shape[0]
         flat = sample.reshape(n, -1).to(self.dtype)
-        tshift = 0.0 if timestep is None else float(timestep) * self.time_scale
+        # the timestep is used as a device scalar (no host read): the call can be captured into a hipGraph and replayed with
+        # another timestep in the same buffer, like a real UNet's timestep embedding
+        tshift = None
+        if timestep is not None:
+            tshift = (timestep if torch.is_tensor(timestep) else torch.tensor(float(timestep))).to(flat.device, torch.float32) * self.time_scale
         xs = {}
         for (s, c) in self.stack.level_shapes():
             tok = (flat @ self.lift[f"{s}_{c}"]).view(n, s, 8)                       # [N, S, 8] tokens ...
-            xs[(s, c)] = (tok.repeat(1, 1, c // 8) + tshift).contiguous()            # ... tiled to the level width
+            wide = tok.repeat(1, 1, c // 8)                                          # ... tiled to the level width
+            xs[(s, c)] = (wide if tshift is None else wide + tshift).contiguous()
         ehs = encoder_hidden_states
         if added_cond_kwargs and added_cond_kwargs.get("image_embeds") is not None:  # IP-Adapter UNets hand (text, [ip])
             ehs = (encoder_hidden_states, list(added_cond_kwargs["image_embeds"]))
@@ -147,6 +152,55 @@ class StackDenoiser(nn.Module):
             out = out + h.reshape(n, s * 8) @ self.drop[f"{s}_{c}"]
         out = (out / len(self.stack.level_shapes())).view_as(sample).to(sample.dtype)
         return (out,)
+
+
+# ---------------------------------------------------------------------------------------------
+class _PassGraphs:
+    """hipGraph capture of the distinct UNet passes of ONE denoising run (the loop it serves is
+    pipeline_interpolated_sd.py:1834-1907).  A run has at most three kinds of pass — conditional with AID on, conditional
+    plain, unconditional (or the two batched variants) — each launching a few hundred kernels per call.  The first call of
+    a kind runs once eagerly (lazy kernel attributes, coefficient buffers, workspaces, the text K / V cache), is captured, and
+    every later step only copies the step's inputs (scaled latents, timestep) into the captured buffers and replays.
+    ``activate_aid(it)`` rewrites the coefficient buffers in place, so a replay reads the live schedule."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = bool(enabled)
+        self._ent: Dict[Any, Tuple] = {}
+
+    def run(self, key, fn: Callable, **inputs: torch.Tensor):
+        if not self.enabled:
+            return fn(**inputs)
+        ent = self._ent.get(key)
+        if ent is None:
+            static = {k: v.clone() for k, v in inputs.items()}
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                fn(**static)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = fn(**static)
+            ent = (graph, static, out)
+            self._ent[key] = ent
+        graph, static, out = ent
+        for k, v in inputs.items():
+            static[k].copy_(v)
+        graph.replay()
+        return out                      # captured output buffer: consume it before the same kind of pass runs again
+
+
+def _use_graphs(flag: Optional[bool], device: torch.device) -> bool:
+    return (device.type == "cuda" and torch.cuda.is_available()) if flag is None else bool(flag)
+
+
+def _dev_scalar(t, device: torch.device) -> torch.Tensor:
+    """The step's timestep as a device tensor (graph input); schedulers hand out device or host scalars."""
+    if torch.is_tensor(t):
+        return t if t.device == device else t.to(device)
+    return torch.tensor(t, device=device)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -176,7 +230,17 @@ class InterpolationStableDiffusionPipeline:
                                                          negative_prompt=negative_prompt)
             return out
         sf = getattr(getattr(pipe.vae, "config", None), "scaling_factor", 0.18215)
-        return cls(pipe.unet, pipe.scheduler, pipe.vae, encode_prompt=enc, vae_scaling_factor=sf)
+        enc_img = None
+        if hasattr(pipe, "prepare_ip_adapter_image_embeds"):
+            def enc_img(image):
+                """(negative, positive) image embeddings of one image, as the reference takes them from diffusers'
+                prepare_ip_adapter_image_embeds with classifier-free guidance on (pipeline_interpolated_sd.py:1763-1802)."""
+                embeds = pipe.prepare_ip_adapter_image_embeds(image, None, pipe._execution_device, 1, True)[0]
+                neg, pos = embeds.chunk(2)
+                return neg, pos
+        obj = cls(pipe.unet, pipe.scheduler, pipe.vae, encode_prompt=enc, encode_image=enc_img, vae_scaling_factor=sf)
+        obj._load_ip_adapter = getattr(pipe, "load_ip_adapter", None)      # diffusers' loader: load_aid_ip_adapter(path, ...) uses it
+        return obj
 
     # -- the reference's AID methods ----------------------------------------------------------------
     def load_aid(self, t: Optional[float] = 0.5, is_fused: bool = True, atype: str = "fused_outer", **kw):
@@ -263,11 +327,13 @@ class InterpolationStableDiffusionPipeline:
                            callback_on_step_end_tensor_inputs: Sequence[str] = ("latents",),
                            # build-specific: embeddings instead of prompt strings / images
                            embeds_start=None, embeds_end=None, embeds_guide=None,
-                           image_embeds_start=None, image_embeds_end=None, **kwargs):
+                           image_embeds_start=None, image_embeds_end=None, use_graphs: Optional[bool] = None, **kwargs):
         """Batch ``[start, target(it), end]`` through the denoising loop (pipeline_interpolated_sd.py:1407-1963).
         ``is_fused`` / ``atype`` are accepted and ignored exactly like the reference (:1418-1419):
         behaviour is set by ``load_aid``.  ``image_embeds_start / _end``: (negative, positive) image-embedding pairs
-        ``[1, 1, emb]`` in place of ``image_start`` / ``image_end`` PIL images (whose encoding is diffusers' job)."""
+        ``[1, 1, emb]`` in place of ``image_start`` / ``image_end`` PIL images (whose encoding is diffusers' job).
+        ``use_graphs`` (build-specific; None = on a GPU): the three kinds of UNet pass of the loop are captured into
+        hipGraphs at their first step and replayed afterwards (:class:`_PassGraphs`); results are bit-identical to eager."""
         if image_start is not None and image_end is None:
             raise ValueError("Please provide both `image_start` and `image_end` to interpolate, or only `image_end` to "
                              "control the scale.")                                     # pipeline_interpolated_sd.py:1608-1612
@@ -297,17 +363,28 @@ class InterpolationStableDiffusionPipeline:
         warmup_steps = int(num_inference_steps * warmup_ratio)                         # :1831
         lat = batch.latents
         cond, unc = batch.cond.to(dev, dtype), batch.uncond.to(dev, dtype)
+        graphs = _PassGraphs(_use_graphs(use_graphs, dev))
+
+        # loop-invariant conditioning, moved to the device once (the reference rebuilds the dict every step, :1850-1867)
+        added_c = self._added_cond(None if pooled is None else pooled[0], 3, None if img is None else img[0])
+        added_u = self._added_cond(None if pooled is None else pooled[1], 3, None if img is None else img[1])
+
+        def cond_pass(x, t):
+            return self._unet(x, t, cond, added_c)
+
+        def uncond_pass(x, t):
+            return self._unet(x, t, unc, added_u)
+
         for i, t in enumerate(self.scheduler.timesteps):
             x = self.scheduler.scale_model_input(lat, t)
+            td = _dev_scalar(t, dev) if graphs.enabled else t
             if i < warmup_steps:                                                       # :1845-1848
                 self.activate_aid(it)
             else:
                 self.deactivate_aid()
-            noise_text = self._unet(x, t, cond, self._added_cond(None if pooled is None else pooled[0], 3,
-                                                                 None if img is None else img[0]))
+            noise_text = graphs.run(("cond", i < warmup_steps), cond_pass, x=x, t=td)
             self.deactivate_aid()                                                      # :1870
-            noise_unc = self._unet(x, t, unc, self._added_cond(None if pooled is None else pooled[1], 3,
-                                                               None if img is None else img[1]))
+            noise_unc = graphs.run(("uncond",), uncond_pass, x=x, t=td)
             noise = noise_unc + gs * (noise_text - noise_unc)                          # :1892
             lat = self.scheduler.step(noise, t, lat, return_dict=False)[0]
             if callback_on_step_end is not None:
@@ -325,13 +402,15 @@ class InterpolationStableDiffusionPipeline:
                     beta: Optional[float] = None, guidance_scale: Optional[float] = None,
                     # build-specific
                     embeds_start=None, embeds_end=None, embeds_guide=None, batched_cfg: bool = True,
-                    output_type: str = "np", coef: Optional[Sequence[float]] = None):
+                    output_type: str = "np", coef: Optional[Sequence[float]] = None, use_graphs: Optional[bool] = None):
         """gradio_src/pipeline_interpolated_stable_diffusion.py:163-304 with the root pipelines' warm-up count
         (``i < int(T * warmup_ratio)`` with 0-based ``i``).  ``late`` must be "self" (plain
         attention) or one of the AID modes.  ``batched_cfg``: the two passes of a step run as one UNet call.
         ``coef`` (build-specific, ``[0, t_1, ..., 1]``): render the frames at THESE coefficients the way
         ``interpolate_single(t_k)`` would — latents slerp'd and embeddings lerp'd at ``t_k``, attention coefficient
-        ``t_k`` — in one N-frame run (the Beta-prior exploration fills several gaps per run with it, prior.py)."""
+        ``t_k`` — in one N-frame run (the Beta-prior exploration fills several gaps per run with it, prior.py).
+        ``use_graphs`` as in ``interpolate_single``.  The processors ``load_aid`` / ``load_aid_ip_adapter`` installed are put
+        back when the run ends (the run works with its own N-frame processors)."""
         if early not in EARLY_MODES or (late != "self" and late not in EARLY_MODES):
             raise ValueError(f"early / late must be in {EARLY_MODES} (late also 'self')")
         gs = self.default_guidance_scale if guidance_scale is None else guidance_scale
@@ -360,36 +439,54 @@ class InterpolationStableDiffusionPipeline:
                     pooled = (linear_interpolation(cond_s[1], cond_e[1], ts=ts), linear_interpolation(unc_s[1], unc_e[1], ts=ts))
         self.scheduler.set_timesteps(num_inference_steps, device=dev)
         warmup_steps = int(num_inference_steps * warmup_ratio)
-        procs = {}
-        for mode in {early} | ({late} - {"self"}):
-            install_sequence_processors(self.unet, size, early=mode, alpha=alpha, beta=beta,
-                                        num_inference_steps=num_inference_steps, coef=batch.coef)
-            procs[mode] = dict(self.unet.attn_processors)
-        cond, unc = batch.cond.to(dev, dtype), batch.uncond.to(dev, dtype)
-        idx = [int(i) for i in batch.ctx_index.tolist()] if batch.n_distinct_ctx != size else None
-        lat = batch.latents
-        for i, t in enumerate(self.scheduler.timesteps):
-            x = self.scheduler.scale_model_input(lat, t)
-            mode = early if i < warmup_steps else late
-            if mode != "self":
-                self.unet.set_attn_processor(procs[mode])
-            else:
-                self.unet.set_attn_processor(procs[early])
+        installed = dict(self.unet.attn_processors)          # what load_aid / load_aid_ip_adapter put there: restored at the end
+        try:
+            procs = {}
+            for mode in {early} | ({late} - {"self"}):
+                install_sequence_processors(self.unet, size, early=mode, alpha=alpha, beta=beta,
+                                            num_inference_steps=num_inference_steps, coef=batch.coef)
+                procs[mode] = dict(self.unet.attn_processors)
+            cond, unc = batch.cond.to(dev, dtype), batch.uncond.to(dev, dtype)
+            idx = [int(i) for i in batch.ctx_index.tolist()] if batch.n_distinct_ctx != size else None
+            lat = batch.latents
+            graphs = _PassGraphs(_use_graphs(use_graphs, dev))
+            ctx_both = torch.cat([cond, unc]) if batched_cfg else None      # ONE tensor for the whole run: the text K / V cache keys on it
             if batched_cfg:
-                set_aid_active(self.unet, mode != "self", plain_tail=size if mode != "self" else 0)
-                set_ctx_index(self.unet, None if idx is None else idx + [j + batch.n_distinct_ctx for j in idx])
-                both = self._unet(torch.cat([x, x]), t, torch.cat([cond, unc]),
-                                  self._added_cond(None if pooled is None else torch.cat(pooled), 2 * size))
-                noise_text, noise_unc = both[:size], both[size:]
+                added_both = self._added_cond(None if pooled is None else torch.cat(pooled), 2 * size)
             else:
-                set_ctx_index(self.unet, idx)
-                set_aid_active(self.unet, mode != "self")
-                noise_text = self._unet(x, t, cond, self._added_cond(None if pooled is None else pooled[0], size))
-                set_aid_active(self.unet, False)
-                noise_unc = self._unet(x, t, unc, self._added_cond(None if pooled is None else pooled[1], size))
-            noise = noise_unc + gs * (noise_text - noise_unc)
-            lat = self.scheduler.step(noise, t, lat, return_dict=False)[0]
-        set_ctx_index(self.unet, None)
+                added_c = self._added_cond(None if pooled is None else pooled[0], size)
+                added_u = self._added_cond(None if pooled is None else pooled[1], size)
+
+            def both_pass(x, t):
+                return self._unet(torch.cat([x, x]), t, ctx_both, added_both)
+
+            def cond_pass(x, t):
+                return self._unet(x, t, cond, added_c)
+
+            def uncond_pass(x, t):
+                return self._unet(x, t, unc, added_u)
+
+            for i, t in enumerate(self.scheduler.timesteps):
+                x = self.scheduler.scale_model_input(lat, t)
+                td = _dev_scalar(t, dev) if graphs.enabled else t
+                mode = early if i < warmup_steps else late
+                self.unet.set_attn_processor(procs[mode] if mode != "self" else procs[early])
+                if batched_cfg:
+                    set_aid_active(self.unet, mode != "self", plain_tail=size if mode != "self" else 0)
+                    set_ctx_index(self.unet, None if idx is None else idx + [j + batch.n_distinct_ctx for j in idx])
+                    both = graphs.run(("both", mode), both_pass, x=x, t=td)
+                    noise_text, noise_unc = both[:size], both[size:]
+                else:
+                    set_ctx_index(self.unet, idx)
+                    set_aid_active(self.unet, mode != "self")
+                    noise_text = graphs.run(("cond", mode), cond_pass, x=x, t=td)
+                    set_aid_active(self.unet, False)
+                    noise_unc = graphs.run(("uncond", mode), uncond_pass, x=x, t=td)
+                noise = noise_unc + gs * (noise_text - noise_unc)
+                lat = self.scheduler.step(noise, t, lat, return_dict=False)[0]
+        finally:
+            set_ctx_index(self.unet, None)
+            self.unet.set_attn_processor(installed)
         return self._decode(lat, output_type)
 
     # -- small shape helpers (overridden by the XL class) ----------------------------------------------

@@ -178,7 +178,7 @@ def extract_uniform_points_plus(features: Sequence[torch.Tensor], interpolation_
     weights = np.full((m, m), -1.0)
     for a in range(m - 1):
         for b in range(a + 1, m):
-            weights[a, b] = float(distance(features[a], features[b]))
+            weights[a, b] = float(distance(features[a], features[b]))       # float() also brings a device scalar to the host
     return find_minimal_spread_and_path(interpolation_size, m, weights)[1]
 
 
@@ -193,7 +193,13 @@ class BetaPriorExplorer:
     def __init__(self, generate: Callable[[List[float]], Tuple[list, List[torch.Tensor]]],
                  distance: Callable = clip_distance):
         self.generate = generate
-        self.distance = distance
+        self._distance = distance
+
+    def distance(self, a, b):
+        """Distance of two feature rows as a HOST scalar: features (and the cosine) stay on the frames' device, the search
+        decisions (widest gap, curve fit) are host arithmetic on 0-dim fp32 values like the reference's."""
+        d = self._distance(a, b)
+        return d.detach().cpu() if torch.is_tensor(d) and d.device.type != "cpu" else d
 
     def explore(self, exploration_size: int = 16, init_alpha: float = 3, init_beta: float = 3, uniform: bool = False,
                 batch: int = 1):
@@ -259,12 +265,26 @@ class BetaPriorPipeline:
 
     @torch.no_grad()
     def _get_feature(self, image):
+        """CLIP image feature of one frame, [1, D] (prior.py:24-33).  With a ``preprocess`` component the frame goes through
+        it the way the reference calls transformers' ``CLIPImageProcessor``: ``preprocess(image, return_tensors="pt"
+        [, do_rescale=False for numpy frames]).pixel_values`` — float frames in [0, 1] must not be rescaled again; uint8
+        frames (what this package's pipelines return for ``output_type="np"``) keep the processor's 1/255 rescale.  The
+        pixel tensor is then moved to the feature model's device and dtype."""
         if self.preprocess is not None:
-            image = self.preprocess(image)
+            kw = {"return_tensors": "pt"}
+            if isinstance(image, np.ndarray) and image.dtype.kind == "f":
+                kw["do_rescale"] = False
+            out = self.preprocess(image, **kw)
+            image = getattr(out, "pixel_values", None)
+            if image is None:
+                image = out["pixel_values"] if isinstance(out, dict) else out
         if not torch.is_tensor(image):
             image = torch.as_tensor(np.asarray(image))
         if image.ndim == 3:
             image = image[None]
+        ref = next(iter(self.model.parameters()), None) if hasattr(self.model, "parameters") else None
+        if ref is not None:
+            image = image.to(ref.device, ref.dtype) if image.is_floating_point() else image.to(ref.device)
         return self.model.get_image_features(image)
 
     def _render(self, ts, prompt_start, prompt_end, negative_prompt, latent_start, latent_end, num_inference_steps, kw):
@@ -276,8 +296,12 @@ class BetaPriorPipeline:
                                                latent_end=latent_end, num_inference_steps=num_inference_steps, **kw)
             frames = out["images"] if isinstance(out, dict) else out.images
         else:
+            # the N-frame run renders with the mode load_aid / load_aid_ip_adapter selected (the batch-3 call above does too)
+            early = getattr(self.pipe, "_aid_early", None)
+            if early not in ("pure_inner", "fused_inner", "pure_outer", "fused_outer"):
+                early = "fused_outer"
             frames = self.pipe.interpolate(latent_start, latent_end, prompt_start, prompt_end,
-                                           negative_prompt=negative_prompt, size=len(ts) + 2,
+                                           negative_prompt=negative_prompt, size=len(ts) + 2, early=early,
                                            num_inference_steps=num_inference_steps, coef=[0.0] + list(ts) + [1.0], **kw)
         frames = [frames[i] for i in range(len(ts) + 2)]
         return frames, [self._get_feature(f) for f in frames]

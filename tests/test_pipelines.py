@@ -197,3 +197,34 @@ def test_load_aid_ip_adapter_wraps_like_the_reference():
     assert all(p.activated and abs(float(p.coef[1]) - 0.25) < 1e-7 for p in unet.attn_processors.values())
     with pytest.raises(ValueError, match="early"):
         pipe.load_aid_ip_adapter(early="nope")
+
+
+def test_from_pipe_wires_the_ip_adapter_loader_and_the_image_encoder():
+    """a wrapped diffusers pipeline must hand over `load_ip_adapter` (so load_aid_ip_adapter(path, ...) can load
+    weights) and an image encoder built on `prepare_ip_adapter_image_embeds` (so image_start / image_end work)."""
+    calls = {}
+
+    class FakeVae:
+        config = type("C", (), {"scaling_factor": 0.13025})()
+
+    class FakePipe:
+        unet, scheduler, vae = object(), object(), FakeVae()
+        _execution_device = "cpu"
+
+        def encode_prompt(self, *a, **k):
+            return ("cond", "uncond")
+
+        def load_ip_adapter(self, path, subfolder=None, weight_name=None, image_encoder_folder=None, **kw):
+            calls["load"] = (path, subfolder, weight_name, image_encoder_folder)
+
+        def prepare_ip_adapter_image_embeds(self, image, embeds, device, n, cfg):
+            calls["img"] = (image, device, n, cfg)
+            return [torch.arange(2 * 1 * 4, dtype=torch.float32).view(2, 1, 4)]
+
+    pipe = aid_amd.InterpolationStableDiffusionPipeline.from_pipe(FakePipe())
+    assert pipe.vae_scaling_factor == 0.13025 and pipe._load_ip_adapter is not None
+    neg, pos = pipe._encode_image("an image")
+    assert calls["img"] == ("an image", "cpu", 1, True)
+    assert neg.tolist() == [[[0.0, 1.0, 2.0, 3.0]]] and pos.tolist() == [[[4.0, 5.0, 6.0, 7.0]]]
+    pipe._load_ip_adapter("h94/IP-Adapter", subfolder="models", weight_name="w.bin", image_encoder_folder="image_encoder")
+    assert calls["load"] == ("h94/IP-Adapter", "models", "w.bin", "image_encoder")

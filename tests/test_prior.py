@@ -88,3 +88,39 @@ def test_beta_prior_pipeline_facade_over_the_pipeline_classes():
     assert set(runs[1]) == {3}                          # batch-3 interpolate_single runs only
     assert max(runs[3]) > 3                             # N-frame runs ([cond ; uncond] batched) fill several gaps
     assert len(runs[3]) < len(runs[1])
+
+
+def test_get_feature_goes_through_the_image_processor_like_the_reference():
+    """with transformers' CLIPImageProcessor as ``preprocess`` the frame must be passed with
+    return_tensors="pt" and the ``pixel_values`` of the returned BatchFeature must reach the model — on the model's
+    device and dtype (reference prior.py:24-33)."""
+    seen = {}
+
+    class BatchFeature(dict):                       # what CLIPImageProcessor returns: a dict with attribute access
+        def __getattr__(self, k):
+            return self[k]
+
+    def processor(image, return_tensors=None, do_rescale=True):
+        seen["kw"] = (return_tensors, do_rescale)
+        x = torch.as_tensor(np.asarray(image)).float()
+        if do_rescale:
+            x = x / 255.0
+        return BatchFeature(pixel_values=x.permute(2, 0, 1)[None])
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3, dtype=torch.float64))
+
+        def get_image_features(self, pixel_values):
+            seen["dtype"], seen["shape"] = pixel_values.dtype, tuple(pixel_values.shape)
+            return pixel_values.mean(dim=(2, 3)) * self.w
+
+    bp = P.BetaPriorPipeline(pipe=None, model=Model(), preprocess=processor)
+    frame_u8 = (np.arange(4 * 5 * 3) % 255).astype(np.uint8).reshape(4, 5, 3)
+    f = bp._get_feature(frame_u8)
+    assert seen["kw"] == ("pt", True) and seen["dtype"] == torch.float64 and seen["shape"] == (1, 3, 4, 5)
+    assert tuple(f.shape) == (1, 3) and float(f.max()) <= 1.0
+    bp._get_feature(frame_u8.astype(np.float32) / 255.0)            # float frames in [0, 1] are not rescaled again
+    assert seen["kw"] == ("pt", False)
+    np.testing.assert_allclose(bp._get_feature(frame_u8.astype(np.float32) / 255.0).detach().numpy(), f.detach().numpy(), rtol=1e-6)
