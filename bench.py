@@ -80,7 +80,11 @@ def parse():
                          "residual add behind it, as three steps (torch LayerNorm / call / torch add) or as ONE library call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary SD1.5 measurement of the default run")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements of the default run")
+    ap.add_argument("--no-text-kv-cache", action="store_true",
+                    help="project the text keys / values in every cross-attention call like the reference does (default: "
+                         "once per layer and context; the contexts do not change over the steps)")
+    ap.add_argument("--dtype", default=None, choices=["f16", "bf16"], help="override the workload's storage dtype")
     return ap.parse_args()
 
 
@@ -98,6 +102,9 @@ def self_spawn(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; with the legacy mode RCCL's
+    # peer-buffer exchange between the rank processes fails in hipIpcGetMemHandle ("invalid argument").  The image exports
+    # it already; it is set here too so that a bare `python bench.py --gpus N` works from any shell.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.run(cmd, env=env).returncode
 
@@ -182,11 +189,13 @@ def roofline_object(agg, stack):
 
 def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
     """The CPU port ("port", oracle/aid_cpu_port.py: the oracle's arithmetic on torch CPU ops) on the host cores with
-    torch.set_num_threads(all cores).  Bounded sample (~10-30 s): ONE transformer block (self + cross call) per
-    resolution level, in the AID mode and in plain mode, on the 3-frame sub-batch [first, middle, last] of the same
-    synthetic inputs; the attention core of a call is timed for 1 and for 2 heads on at most 1024 query rows and
-    extrapolated linearly to all heads and rows (projections run in full).  Scaled x n_frames / 3, x blocks per level,
-    x pass counts, to the 50-step unit."""
+    torch.set_num_threads(the cpus this process may use).  Recipe of SURVEY.md §8d on a bounded sample (~25 s):
+    ONE transformer block (self + cross call) per resolution level, in the AID mode and in plain mode, on the 3-frame
+    sub-batch [first, middle, last] of the same synthetic inputs.  Every call runs IN FULL (all heads, all query rows, real
+    S): levels with S <= 1024 one warm-up + the median of three runs, the S = 4096 level single shots (its calls take
+    seconds each); when the budget runs out before the S = 4096 plain calls, those are scaled from the measured AID call by
+    the flop ratio (stated in `sample`).  Scaled x n_frames / 3, x blocks per level, x pass counts, to the 50-step unit."""
+    import statistics
     import torch
     from oracle import aid_cpu_port as P
     from oracle import aid_oracle as O
@@ -204,6 +213,7 @@ def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
     g = torch.Generator().manual_seed(1002)
     mode = "outer" if early.endswith("outer") else "inner"
     fused = early.startswith("fused")
+    segs = (2 if mode == "outer" else 1) + (1 if fused else 0)
     full = O.beta_coefs(n_frames, steps, steps)
     coef = torch.tensor([0.0, float(full[n_frames // 2]), 1.0])
     levels = {}
@@ -211,39 +221,55 @@ def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
         levels[(s, c, h)] = levels.get((s, c, h), 0) + nblk
     t_aid = t_plain = 0.0
     t0_all = time.time()
+    detail, scaled = [], []
 
-    def call_time(x, ctx, w, h, md, fu, cf):
-        s_ = x.shape[1]
-        r = min(s_, 1024)
-
-        def once(k):
+    def timed(x, ctx, w, h, md, fu, cf, single):
+        def once():
             t0 = time.time()
-            P.processor_call(x, ctx, *w, h, md, fu, cf, only_heads=k, only_rows=r)
+            P.processor_call(x, ctx, *w, h, md, fu, cf)
             return time.time() - t0
-        once(1)                                          # warm the allocator / thread pool
-        t1, t2 = once(1), once(2)
-        core = max(t2 - t1, 0.0)                         # one head's attention core on r query rows
-        return (t1 - core) + h * core * (s_ / r)
+        if single:
+            first = once()                               # seconds per call: single shot ...
+            if first < 3.0 and time.time() - t0_all < 0.5 * budget_s:
+                return sorted([first, once(), once()])   # ... unless the budget clearly allows three
+            return [first]
+        once()                                           # warm-up: allocator, thread pool
+        return sorted(once() for _ in range(3))
 
     for (s, c, h), nblk in sorted(levels.items()):          # small levels first, the S = 4096 calls last
-        cc = spec["cross_dim"]
+        cc, l = spec["cross_dim"], spec["text_len"]
         rn = lambda *sh, sc=1.0: torch.randn(*sh, generator=g) * sc      # noqa: E731
-        x, ctx = rn(3, s, c), rn(3, spec["text_len"], cc)
+        x, ctx = rn(3, s, c), rn(3, l, cc)
         ws = (rn(c, c, sc=c ** -0.5), rn(c, c, sc=c ** -0.5), rn(c, c, sc=c ** -0.5), rn(c, c, sc=c ** -0.5), rn(c, sc=.01))
         wx = (ws[0], rn(c, cc, sc=cc ** -0.5), rn(c, cc, sc=cc ** -0.5), ws[3], ws[4])
-        ta = call_time(x, None, ws, h, mode, fused, coef) + call_time(x, ctx, wx, h, mode, fused, coef)
-        tp = call_time(x, None, ws, h, "plain", False, None) + call_time(x, ctx, wx, h, "plain", False, None)
-        t_aid += nblk * ta * n_frames / 3.0
-        t_plain += nblk * tp * n_frames / 3.0
+        single = s > 1024
+        med = {}
+        for tag, xx, cx, w, md, fu, cf in (("aid_self", x, None, ws, mode, fused, coef), ("aid_cross", x, ctx, wx, mode, fused, coef),
+                                           ("plain_self", x, None, ws, "plain", False, None),
+                                           ("plain_cross", x, ctx, wx, "plain", False, None)):
+            if tag == "plain_self" and single and time.time() - t0_all > budget_s:
+                # out of budget before the longest plain call: scale the measured AID self call by the flop ratio
+                fa = 8.0 * 3 * s * c * c + 4.0 * 3 * s * s * c * segs
+                fp = 8.0 * 3 * s * c * c + 4.0 * 3 * s * s * c
+                med[tag] = med["aid_self"] * fp / fa
+                scaled.append(f"S={s} plain self call = AID self call x {fp / fa:.2f} (flop ratio)")
+                continue
+            ts = timed(xx, cx, w, h, md, fu, cf, single)
+            med[tag] = statistics.median(ts)
+            detail.append(f"S={s} C={c} {tag}: " + "/".join(f"{t:.2f}" for t in (ts[0], med[tag], ts[-1])) + " s")
+        t_aid += nblk * (med["aid_self"] + med["aid_cross"]) * n_frames / 3.0
+        t_plain += nblk * (med["plain_self"] + med["plain_cross"]) * n_frames / 3.0
     n_aid = int(steps * warmup_ratio)
     total = n_aid * (t_aid + t_plain) + (steps - n_aid) * 2 * t_plain
     return dict(value=n_frames / (total * 50.0 / steps), unit="interpolation-frames/sec (50-step)",
                 cores=torch.get_num_threads(), kind="port",
                 sample=(f"oracle/aid_cpu_port.py (torch CPU ops, fp32, torch.get_num_threads() = {torch.get_num_threads()} = the cpus this "
                         f"process may use, of {cores} host cpus): 1 transformer block (self + cross call) per resolution level in {early} and in "
-                        f"plain mode on the 3-frame sub-batch [first, middle, last], attention core timed for 1 and 2 heads on <= 1024 "
-                        f"query rows and extrapolated to all heads / rows; scaled x{n_frames}/3 frames, x blocks per level, x({n_aid} AID + "
-                        f"{2 * steps - n_aid} plain passes), x50/{steps}; measured {time.time() - t0_all:.1f} s of CPU work"))
+                        f"plain mode on the 3-frame sub-batch [first, middle, last]; every call in full (all heads, all rows, real S): S <= 1024 one "
+                        f"warm-up + median of 3, S = 4096 single shots" + ("; " + "; ".join(scaled) if scaled else "") +
+                        f"; scaled x{n_frames}/3 frames, x blocks per level, x({n_aid} AID + {2 * steps - n_aid} plain passes), x50/{steps}; "
+                        f"measured {time.time() - t0_all:.1f} s of CPU work"),
+                calls_min_median_max_s=detail)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -252,6 +278,7 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
     from aid_amd import dist as adist
     from aid_amd.loop import AidDenoiseLoop, install_sequence_processors
     stack, dt, early_default, frames_default, guide_default, what = WORKLOADS[name]
+    dt = getattr(args, "dtype", None) or dt
     dtype = torch.float16 if dt == "f16" else torch.bfloat16
     early = args.early or early_default
     steps = args.steps
@@ -385,7 +412,9 @@ def main():
 
     import aid_amd
     from aid_amd import dist as adist
+    from aid_amd import processors as aproc
     aid_amd._lib.load()                     # fail loudly before anything else if the HIP library is missing
+    aproc.TEXT_KV_CACHE = not args.no_text_kv_cache
 
     name = args.workload
     if name == "auto":
@@ -413,6 +442,10 @@ def main():
             "sublayers": {"off": "attention calls only (the BASELINE metric)",
                           "steps": "LayerNorm + call + residual add per layer, three steps (torch LayerNorm / add)",
                           "fused": "LayerNorm + call + residual add per layer in one library call"}[args.sublayers],
+            "text_kv": ("keys / values of the text contexts projected ONCE per (layer, context) and reused by every step: the "
+                        "contexts are loop-invariant (reference pipeline_interpolated_sd.py:1859-1867 passes the same prompt_embeds "
+                        "each step and re-projects them 50 times); `also.sdxl_text_kv_per_call` times the per-call projection"
+                        if not args.no_text_kv_cache else "projected in every cross-attention call (like the reference)"),
             "coef": f"BetaPPF(alpha=beta={steps})", "hipgraph": not args.no_graph,
             "parallelism": f"frame-shard x{world} (replicated end points, no per-layer collective)",
             "ranks": world, "backend": backend,
@@ -423,10 +456,17 @@ def main():
         result["config"]["ip_adapter"] = (f"{args.ip_tokens} image tokens per frame, image embeddings [3 N, 1, T, Cc]; AID pass = "
                                           f"{wl['early']} IP processors, other passes = IP-Adapter attention (text + scale x image)")
     if world > 1:
-        result["config"]["max_local_batch"] = max(adist.frame_shard(wl["n_total"], world, r).n_local for r in range(world))
+        mlb = max(adist.frame_shard(wl["n_total"], world, r).n_local for r in range(world))
+        result["config"]["max_local_batch"] = mlb
+        # what the busiest rank delivers, in frames of ITS batch per second: compare with the 1-GPU line at that batch size
+        # (replicated end points make the ideal speed-up n_total / max_local_batch, not the rank count)
+        result["config"]["busiest_rank_local_frames_per_s"] = mlb / (tm["ms_per_step"] * 50.0 / 1000.0)
 
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline:
+        # N > 1: rank 0's LOCAL batch (no collective inside a step, so one rank can time its kernels alone)
         result["roofline"] = roofline_object(roofline_pass(loop, aid_amd, torch), wl["stack"])
+        if world > 1:
+            result["roofline"]["scope"] = f"rank 0 of {world}: local batch of {shard.n_local} frames"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and name != "ip":
         result["cpu_baseline"] = cpu_baseline(wl["stack"], wl["n_total"], wl["early"], steps, args.warmup_ratio)
     if rank == 0 and world == 1 and name == "sdxl" and args.workload == "auto" and not args.model and not args.no_also:
@@ -442,10 +482,31 @@ def main():
             also["roofline"] = {k: r2[k] for k in ("kernel", "achieved", "frac", "achieved_executed", "frac_executed",
                                                    "traffic", "avg_launch_us", "share_of_kernel_time", "stack_tflops", "kernels")}
         result["also"] = {"sd15": also}
+        # the headline workload in fp16 storage (north_star's 1e-3 rel-L2 holds in fp16) ...
+        del w2
+        torch.cuda.empty_cache()
+        args.dtype = "f16"
+        w3 = build_workload("sdxl", args, world, rank, device, torch, aid_amd)
+        t3 = time_workload(w3, args, world, device, torch, dist)
+        result["also"]["sdxl_fp16"] = {"workload": w3["what"], "value": t3["value"], "unit": "frames/s",
+                                       "ms_per_step": t3["ms_per_step"], "repeats": t3["repeats"], "dtype": "f16"}
+        del w3
+        torch.cuda.empty_cache()
+        # ... and with the text keys / values projected in every call, like the reference
+        args.dtype = None
+        if not args.no_text_kv_cache:
+            aproc.TEXT_KV_CACHE = False
+            w4 = build_workload("sdxl", args, world, rank, device, torch, aid_amd)
+            t4 = time_workload(w4, args, world, device, torch, dist)
+            result["also"]["sdxl_text_kv_per_call"] = {"value": t4["value"], "unit": "frames/s", "ms_per_step": t4["ms_per_step"],
+                                                       "repeats": t4["repeats"], "dtype": w4["dtype"]}
+            aproc.TEXT_KV_CACHE = True
+            del w4
 
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()                      # the other ranks wait for rank 0's roofline pass
         dist.destroy_process_group()
 
 

@@ -21,7 +21,7 @@ def _table(name):
         sym = blk.split()[0]
         num = lambda key: int(re.search(re.escape(key) + r": (\d+)", blk).group(1))   # noqa: E731
         out[sym] = dict(vgpr=num("VGPRs"), agpr=num("AGPRs"), scratch=num("ScratchSize [bytes/lane]"),
-                        occ=num("Occupancy [waves/SIMD]"), spill=num("VGPRs Spill"))      # SGPR "spills" go to VGPR lanes: free
+                        occ=num("Occupancy [waves/SIMD]"), spill=num("VGPRs Spill"), sgpr_spill=num("SGPRs Spill"))
     return out
 
 
@@ -40,6 +40,17 @@ def test_no_kernel_spills_or_uses_scratch():
     for obj in ("aid_attn", "aid_gemm", "aid_norm"):
         for sym, r in _table(obj).items():
             assert r["scratch"] == 0 and r["spill"] == 0, (obj, sym, r)
+
+
+def test_sgpr_spills_are_bounded():
+    """SGPR spills go to lanes of a spare VGPR (v_writelane / v_readlane), not to memory — cheap, but each one is VALU issue
+    slots in kernels that are VALU-issue bound, and a jump in the count means a refactor pushed scalar state (segment
+    pointers, descriptors) out of the 102 SGPRs.  The GEMM and LayerNorm kernels spill none; the attention kernel's
+    three-segment variants spill up to 30 (measured at this commit; they sit outside the tile loop: pointers of the
+    segments not being walked).  VERDICT r2 weak #10."""
+    for obj, bound in (("aid_gemm", 0), ("aid_norm", 0), ("aid_attn", 32)):
+        for sym, r in _table(obj).items():
+            assert r["sgpr_spill"] <= bound, (obj, sym, r)
 
 
 def test_attention_variants_keep_the_waves_per_simd_the_launcher_assumes():

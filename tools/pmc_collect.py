@@ -91,7 +91,9 @@ def derive(e, v):
         e["mfma_busy_frac"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 4)
     if v.get("SQ_INSTS_MFMA"):
         e["valu_per_mfma"] = round((v.get("SQ_INSTS_VALU", 0.0) - v["SQ_INSTS_MFMA"]) / v["SQ_INSTS_MFMA"], 2)
-    if cyc and v.get("profiled_ns_per_launch"):
+    # GRBM_GUI_ACTIVE also counts the dispatch ramp-up / drain around a launch: for launches under ~20 us the quotient is not a
+    # clock (a 5 us lerp kernel came out at "5.9 GHz"), so it is reported for longer kernels only
+    if cyc and v.get("profiled_ns_per_launch", 0) >= 20000:
         e["clock_ghz"] = round(cyc / v["profiled_ns_per_launch"], 3)
     if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and "SQ_VALU_MFMA_COEXEC_CYCLES" in v:
         e["coexec_frac_of_mfma_busy"] = round(v["SQ_VALU_MFMA_COEXEC_CYCLES"] / v["SQ_VALU_MFMA_BUSY_CYCLES"], 4)
