@@ -786,6 +786,296 @@ struct PingPong : Engine<T, 256, 256, 64, 2, 2, 4> {
 constexpr int PP_SMALL_NS = 4;
 static_assert(Engine<bf16, 128, 128, 64, PP_SMALL_NS, 2, 4>::SMEM <= PingPong<bf16>::SMEM, "small tiles use the big tile's LDS");
 
+
+// ---- 288 x 256 tile on the same eight waves --------------------------------------------------------------------
+// The projection launches of the SDXL stack are 1.09 (out projection, cross-attention query: 280 tiles of 256 x 256 on
+// 256 CUs) and 3.28 CU rounds (q / k / V^T: 840 tiles): a quarter of the out projection's time is the tail of cut-up tiles,
+// an eighth of the grouped launch is the idle part of its last round.  With 288 rows per tile the same launches are
+// 250 tiles (0.98 rounds) and 750 (2.93): whole rounds, 9 / 8 of the work per tile.
+// The extra 32 rows cost no new wave roles: the strip is 32 x 256 = eight 32 x 32 blocks, ONE per wave, and wave
+// (wr, wc) takes the block over ITS OWN B fragment fb[wr] (columns 64 wc + 32 wr), so the strip needs 4 more A fragment
+// reads per K tile and wave (rows 256 .. 287, read by everybody), 4 more MFMAs (spread over phase 1, one per four main
+// MFMAs: the chain on the ninth accumulator never stalls) and 16 more accumulator registers (144 + 80 fragments).
+// LDS: each parity grows by the strip's 32 rows x 128 B (4 DMA pieces per K tile, issued by waves 0 - 3 with the A halves).
+template <typename T>
+struct PingPongX : PingPong<T> {
+    typedef PingPong<T> PP;
+    typedef typename Vec<T>::v8 T8;
+    typedef typename Vec<T>::v4 T4;
+    static constexpr int BMX = 288, XR = 32;
+    static constexpr int HALF = PP::HALF;
+    static constexpr int STGX = 4 * HALF + XR * 128;            // one parity: A0 A1 B0 B1 + the strip
+    static constexpr int CLD = 256 + 8;
+    static constexpr size_t LNS = (size_t)(BMX + 256) * 2 * sizeof(float);
+    static constexpr size_t SMEMX = (size_t)BMX * CLD * 2 + LNS > (size_t)2 * STGX ? (size_t)BMX * CLD * 2 + LNS : (size_t)2 * STGX;
+    static_assert(SMEMX <= 160 * 1024, "one workgroup per CU");
+    using PP::smem; using PP::tid; using PP::lane; using PP::wave; using PP::wm; using PP::wn; using PP::wr;
+    using PP::l31; using PP::hi; using PP::aoff; using PP::boff; using PP::ax; using PP::bx; using PP::acc;
+    using PP::ra; using PP::rb; using PP::avo; using PP::bvo;
+    f32x16 accx;
+    int xoff, xx, xvo;
+
+    __device__ __forceinline__ void init(char* smem_) {
+        PP::init(smem_);
+        xoff = 4 * HALF + l31 * 128;                            // strip row l31 inside a parity
+        xx = hi ^ PP::swz(l31);
+    }
+    __device__ __forceinline__ void set_tile(const GemmDesc& P, const T* A, const T* B, int m0, int n0) {
+        PP::set_tile(P, A, B, m0, n0);
+        const int lrow = 8 * (wave & 3) + (lane >> 3);          // piece `wave` (0 .. 3) of the strip: 8 rows x 128 B
+        const int c = (lane & 7) ^ PP::swz(lrow);
+        xvo = min(256 + lrow, P.m - 1 - m0) * (P.lda * 2) + c * 16;
+    }
+    __device__ __forceinline__ void zero_acc() {
+        PP::zero_acc();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+    }
+    // the four half-tiles live at the same offsets as in PingPong, parities are STGX apart
+    __device__ __forceinline__ void xdma_half(const int Q, int t, int kb) {     // Q is a literal at every call site
+        const bool IS_A = Q >= 2;
+        const int H = Q & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            char* dst = smem + (t & 1) * STGX + (IS_A ? 0 : 2 * HALF) + H * HALF + wave * 2048 + j * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_A ? ra : rb, (__attribute__((address_space(3))) void*)dst, 16,
+                                                     IS_A ? avo[H * 2 + j] : bvo[H * 2 + j], (kb + t) * 128, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void dma_strip(int t, int kb) {  // waves 0 - 3 only
+        char* dst = smem + (t & 1) * STGX + 4 * HALF + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, xvo, (kb + t) * 128, 0, 0);
+    }
+    __device__ __forceinline__ void read_x(T8 (&fx)[4], const char* st) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fx[ks] = *reinterpret_cast<const T8*>(st + xoff + (((2 * ks) ^ xx) << 4));
+    }
+    // counted wait of a read slot: waves 0 - 3 carry one more DMA (the strip piece) per K tile in the A group
+    template <int N>
+    __device__ __forceinline__ void wait_rd(bool xw) {
+        if (xw) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N + 1) : "memory");
+        else    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    }
+
+    // The K loop of PingPong::mac_rd with the strip: stream per wave  B(0) A(0) X(0) B(1) | A(1) X(1) B(2) | A(2) X(2) B(3) ...
+    //   READ-P0(kt): reads B0 B1 A0 of kt, requests A0 A1 X of kt + 1, retires A1(kt), X(kt)   (newer: B(kt+1) A(kt+1) X(kt+1))
+    //   READ-P1(kt): reads A1(kt), X(kt), requests B0 B1 of kt + 2, retires B(kt+1), A0(kt+1)  (newer: A1(kt+1) X(kt+1) B(kt+2))
+    template <int WR>
+    __device__ __forceinline__ void mac_x(int kb, int ke) {
+        const int nk = ke - kb;
+        const bool xw = wave < 4;
+        xdma_half(0, 0, kb); xdma_half(1, 0, kb); xdma_half(2, 0, kb); xdma_half(3, 0, kb);
+        if (xw) dma_strip(0, kb);
+        if (nk > 1) {
+            xdma_half(0, 1, kb); xdma_half(1, 1, kb);
+            if (xw) wait_vmcnt<7>(); else wait_vmcnt<6>();      // B(0), A0(0) landed; A1(0) [X(0)] B(1) may fly
+        } else {
+            if (xw) wait_vmcnt<3>(); else wait_vmcnt<2>();
+        }
+        PP::slot();
+        if (WR == 1) PP::slot();            // the second group runs one barrier behind
+        T8 fa[2][4], fb[2][4], fx[4];
+        auto body = [&](int kt, auto more1_t, auto more2_t) __attribute__((always_inline)) {
+            constexpr bool M1 = decltype(more1_t)::value, M2 = decltype(more2_t)::value;   // tile kt + 1 / kt + 2 exists
+            const char* st = smem + (kt & 1) * STGX;
+            this->read_b(fb, st);
+            this->read_a(fa, st, 0);
+            if (M1) {
+                xdma_half(2, kt + 1, kb); xdma_half(3, kt + 1, kb);
+                if (xw) dma_strip(kt + 1, kb);
+                wait_rd<8>(xw);
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            PP::slot();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ks = i >> 2, in = (i >> 1) & 1, e = i & 1;
+                acc[in][e] = mfma32(fb[in][ks], fa[e][ks], acc[in][e]);
+            }
+            PP::slot();
+            this->read_a(fa, st, 1);
+            read_x(fx, st);
+            if (M2) {
+                xdma_half(0, kt + 2, kb); xdma_half(1, kt + 2, kb);
+                wait_rd<6>(xw);
+            } else if (M1) {
+                wait_rd<2>(xw);
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            PP::slot();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ks = i >> 2, in = (i >> 1) & 1, e = i & 1;
+                acc[in][2 + e] = mfma32(fb[in][ks], fa[e][ks], acc[in][2 + e]);
+                if ((i & 3) == 3) accx = mfma32(fb[WR][ks], fx[ks], accx);      // the strip's block: this wave's own B fragment
+            }
+            PP::slot();
+        };
+        const std::true_type Y{};
+        const std::false_type N{};
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) body(kt, Y, Y);
+        if (kt + 1 < nk) { body(kt, Y, N); ++kt; }
+        if (kt < nk) body(kt, N, N);
+        if (WR == 0) PP::slot();
+        wait_vmcnt<0>();
+        __syncthreads();                    // everyone is done reading the ring
+    }
+    __device__ __forceinline__ void mac(int kb, int ke) {
+        if (wr == 0) mac_x<0>(kb, ke);      // two copies of the loop: fb[WR] must be a compile-time register choice
+        else         mac_x<1>(kb, ke);
+    }
+
+    // Epilogue of Engine::store_tile for nine blocks per wave and 288 tile rows.
+    __device__ __forceinline__ void store_tile(const GemmDesc& P, T* C, int m0, int n0, const T* R = nullptr,
+                                               const float* stats = nullptr) {
+        constexpr int NTHR = 512, BN = 256;
+        T* Cs = reinterpret_cast<T*>(smem);        // [BMX][CLD]
+        mfma_fence(acc);
+        asm volatile("" : "+v"(accx));
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        asm volatile("" : "+v"(accx));
+        const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
+        const bool bias_vec = (reinterpret_cast<uintptr_t>(bias) & 7) == 0;
+        const int side = stats ? P.ln_side : 0;
+        float* const lnr = reinterpret_cast<float*>(smem + (size_t)BMX * CLD * 2);    // [BMX][2]
+        float* const lnc = lnr + 2 * BMX;                                             // [BN][2]
+        if (side) {
+            for (int i = tid; i < BMX + BN; i += NTHR) {
+                const bool isrow = i < BMX;
+                const int gi = isrow ? min(m0 + i, P.m - 1) : min(n0 + i - BMX, P.n - 1);
+                float q0, q1;
+                if (isrow == (side == 1)) { q0 = stats[2 * gi]; q1 = stats[2 * gi + 1]; }
+                else                      { q0 = P.ln_colsum[gi]; q1 = P.ln_shift[gi]; }
+                lnr[2 * i] = q0;
+                lnr[2 * i + 1] = q1;
+            }
+            __syncthreads();
+        }
+        // one 32 x 32 accumulator block: tile rows rb + l31, columns cb + 8 gq + 4 hi + e
+        auto stage = [&](const f32x16& a, int rb, int cb) __attribute__((always_inline)) {
+            const int row = rb + l31;
+            float lr0 = 0.f, lr1 = 0.f;
+            if (side) { lr0 = lnr[2 * row]; lr1 = lnr[2 * row + 1]; }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int nl = cb + gq * 8 + hi * 4;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = a[gq * 4 + e];
+                if (side) {
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(lnc + 2 * nl);
+                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(lnc + 2 * nl + 4);
+                    const float lc0[4] = {p0[0], p0[2], p1[0], p1[2]}, lc1[4] = {p0[1], p0[3], p1[1], p1[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {       // scalar FMAs on purpose (Engine::store_tile)
+                        float t = side == 1 ? fmaf(-lr0, lc0[e], v[e]) : fmaf(-lc0[e], lr0, v[e]);
+                        asm volatile("" : "+v"(t));
+                        v[e] = side == 1 ? fmaf(lr1, t, lc1[e]) : fmaf(lc1[e], t, lr1);
+                    }
+                }
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+                    if (bias_vec && n0 + nl + 4 <= P.n) {
+                        bv = up4<T>(*reinterpret_cast<const T4*>(bias + n0 + nl));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n0 + nl + e < P.n) bv[e] = (float)bias[n0 + nl + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], P.scale, bv[e]);
+                *reinterpret_cast<T4*>(Cs + row * CLD + nl) = cvt4<T>(v);
+            }
+        };
+#pragma unroll
+        for (int in = 0; in < 2; ++in)
+#pragma unroll
+            for (int im = 0; im < 4; ++im) stage(acc[in][im], wm + im * 32, wn + in * 32);
+        stage(accx, 256, wn + wr * 32);
+        __syncthreads();
+        const bool vec_ok = (P.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+        constexpr int CPRW = BN / 8;               // 16-B chunks per C row
+#pragma unroll
+        for (int it = 0; it < (BMX * CPRW) / NTHR; ++it) {
+            const int id = tid + it * NTHR;
+            const int row = id / CPRW, ch = (id % CPRW) * 8;
+            const int m = m0 + row, n = n0 + ch;
+            if (m >= P.m || n >= P.n) continue;
+            T8 v = *reinterpret_cast<const T8*>(Cs + row * CLD + ch);
+            T* dst = C + (int64_t)m * P.ldc + n;
+            const T* res = R ? R + (int64_t)m * P.ldc + n : nullptr;
+            if (vec_ok && n + 8 <= P.n) {
+                if (res) {
+                    const bool rvec = (reinterpret_cast<uintptr_t>(R) & 15) == 0;
+                    T8 r;
+                    if (rvec) {
+                        r = *reinterpret_cast<const T8*>(res);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) r[e] = res[e];
+                    }
+                    const f32x8 a = up8<T>(v), b = up8<T>(r);
+                    v = cvt8<T>(a + b);
+                }
+                *reinterpret_cast<T8*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < P.n) dst[e] = res ? (T)((float)v[e] + (float)res[e]) : v[e];
+            }
+        }
+    }
+};
+static_assert((288 * 32) % 512 == 0, "C rows divide over the threads");
+static_assert(Engine<bf16, 128, 128, 64, 4, 2, 4>::SMEM <= PingPongX<bf16>::SMEMX, "side tiles use the big tile's LDS");
+
+template <typename T>
+__global__ __launch_bounds__(512) void aid_gemm_nt_ppx_kernel(const GemmGroup g, const GemmSide sd) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if ((int)blockIdx.x < sd.pad_tiles) {                          // side problems first (see aid_gemm_nt_pp_kernel)
+        const int u = blockIdx.x;
+        if (u >= sd.tiles) return;
+        int pi = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i < sd.n && u >= sd.tile_start[i]) pi = i;
+        const GemmDesc& P = sd.p[pi];
+        int rem = u - sd.tile_start[pi];
+        const int tiles_n = (P.n + 127) / 128, per_batch = ((P.m + 127) / 128) * tiles_n;
+        const int batch = rem / per_batch;
+        rem -= batch * per_batch;
+        const int m0 = (rem / tiles_n) * 128, n0 = (rem % tiles_n) * 128;
+        const T* A = reinterpret_cast<const T*>(P.a) + (int64_t)batch * P.stride_a;
+        const T* B = reinterpret_cast<const T*>(P.b) + (int64_t)batch * P.stride_b;
+        T* C = reinterpret_cast<T*>(P.c) + (int64_t)batch * P.stride_c;
+        Engine<T, 128, 128, 64, 4, 2, 4> e;
+        e.init(smem_raw);
+        e.set_tile(P, A, B, m0, n0);
+        e.zero_acc();
+        e.mac(0, P.k / 64);
+        e.store_tile(P, C, m0, n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)batch * P.stride_c : nullptr,
+                     P.ln_stats ? P.ln_stats + 2 * (int64_t)batch * P.stride_stats : nullptr);
+        return;
+    }
+    const int b = blockIdx.x - sd.pad_tiles;
+    const TileCoord tc = locate_pos<288, 256>(g, xcd_remap(b, (int)gridDim.x - sd.pad_tiles));
+    const GemmDesc& P = g.p[tc.p];
+    const T* A = reinterpret_cast<const T*>(P.a) + (int64_t)tc.batch * P.stride_a;
+    const T* B = reinterpret_cast<const T*>(P.b) + (int64_t)tc.batch * P.stride_b;
+    T* C = reinterpret_cast<T*>(P.c) + (int64_t)tc.batch * P.stride_c;
+    PingPongX<T> e;
+    e.init(smem_raw);
+    e.set_tile(P, A, B, tc.m0, tc.n0);
+    e.zero_acc();
+    e.mac(0, P.k / 64);
+    e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr,
+                 P.ln_stats ? P.ln_stats + 2 * (int64_t)tc.batch * P.stride_stats : nullptr);
+}
+
 template <typename T, int PPV>
 __global__ __launch_bounds__(512) void aid_gemm_nt_pp_kernel(const GemmGroup g, const int n_big, const GemmSide sd) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -971,6 +1261,36 @@ static hipError_t launch_pp(GemmGroup& g, hipStream_t stream, const PpPlan& pl, 
     }
 }
 
+
+template <typename T>
+static hipError_t launch_ppx(GemmGroup& g, hipStream_t stream, const GemmSide& sd) {
+    static PerDevice<bool> attr_set;
+    const int tiles = plan_tiles(g, 288, 256);
+    if (tiles <= 0) return hipSuccess;
+    bool* done = attr_set.slot();
+    if (!done) return hipErrorInvalidDevice;
+    if (!*done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(aid_gemm_nt_ppx_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PingPongX<T>::SMEMX);
+        if (e != hipSuccess) return e;
+        *done = true;
+    }
+    hipLaunchKernelGGL(aid_gemm_nt_ppx_kernel<T>, dim3(sd.pad_tiles + tiles), dim3(512), PingPongX<T>::SMEMX, stream, g, sd);
+    return hipGetLastError();
+}
+
+// 288-row tiles pay when they turn a ragged last round into whole rounds: cost in rounds of a 256 x 256 tile, a 288-row
+// tile counted 9 / 8.  GEMM_TRI: 0 = never, 1 = whenever the shape allows (development knob; the name is historical).
+static bool prefer_ppx(GemmGroup& g, int ncu, const PpPlan& pl256) {
+    const int knob = tune(TUNE_GEMM_TRI);
+    if (knob == 0) return false;
+    GemmGroup t = g;
+    const int tiles = plan_tiles(t, 288, 256);
+    const double r288 = 1.125 * (double)((tiles + ncu - 1) / ncu);
+    if (knob == 1) return true;
+    return r288 < 0.97 * pl256.rounds;
+}
+
 // Two engines serve the k % 64 == 0 shapes; which one a launch gets is decided by a two-line cost model fitted to
 // the ten projection launches of the SD1.5 / SDXL stacks (tools/kbench_proj.py, profiles/r01_gemm_variants.txt; it
 // picks the measured winner on all ten):
@@ -1035,6 +1355,11 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** var
                 sd.n = ns;
                 sd.tiles = st;
                 sd.pad_tiles = (st + 7) / 8 * 8;
+                if (prefer_ppx(gm, ncu, plm)) {
+                    if (variant) *variant = "pingpong288+side128";
+                    return launch_ppx<T>(gm, stream, sd);
+                }
+                plan_pp(gm, ncu, nk);                       // back to 256 x 256 tile units
                 if (variant) *variant = plm.n_small ? "pingpong256+tail128+side128" : "pingpong256+side128";
                 return launch_pp<T>(gm, stream, plm, sd);
             }
@@ -1052,6 +1377,11 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** var
         if (force == 31) pp = true;
     }
     if (force == 7) pp = false;
+    if (pp && prefer_ppx(g, ncu, pl)) {
+        if (variant) *variant = "pingpong288";
+        return launch_ppx<T>(g, stream, sd);
+    }
+    if (pp) plan_pp(g, ncu, g.p[0].k / 64);             // g.tile_start back in 256 x 256 units
     if (variant) *variant = !pp ? "lockstep128" : pl.n_small ? "pingpong256+tail128" : "pingpong256";
     if (pp) return launch_pp<T>(g, stream, pl, sd);
     return launch_pipe<T, 128, 128, 64, 2, 2, 4>(g, stream);       // 8 waves, 64 x 32 wave tiles, 2 workgroups / CU

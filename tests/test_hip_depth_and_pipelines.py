@@ -62,10 +62,13 @@ def _oracle_layer(stack, i, h64, ctx64, mode, fused, coef):
 # One sublayer measures ~3e-4 (fp16) / ~2.5e-3 (bf16) on the attention term; the stream itself is re-rounded to the
 # storage dtype after every layer (eps/2 = 2.4e-4 fp16, 2e-3 bf16 relative per rounding), errors add in quadrature over
 # the L layers of a level.  Bounds = ~2x the measured values (gpurun_out/depth_parity.json, profiles/r02_depth_parity.json).
-DEPTH_BOUND = {"sd15": 2e-3, "sdxl": 3e-2}
+# SDXL in fp16 storage (the kernels serve d = 64 in both dtypes): the 140-layer stream stays at the fp16 level — this is the
+# configuration that meets north_star's 1e-3 per layer; bf16 pays 8x the rounding step.
+DEPTH_BOUND = {("sd15", torch.float16): 2e-3, ("sdxl", torch.bfloat16): 3e-2, ("sdxl", torch.float16): 4e-3}
 
 
-@pytest.mark.parametrize("model,dtype,early", [("sd15", torch.float16, "fused_inner"), ("sdxl", torch.bfloat16, "fused_outer")])
+@pytest.mark.parametrize("model,dtype,early", [("sd15", torch.float16, "fused_inner"), ("sdxl", torch.bfloat16, "fused_outer"),
+                                               ("sdxl", torch.float16, "fused_outer")])
 def test_depth_parity_chained_through_every_layer(model, dtype, early):
     n = 7 if model == "sd15" else 5
     stack = aid_amd.AttnStackUNet(model, dtype=dtype, device=DEV, scale_down=16 if model == "sd15" else 32)
@@ -89,11 +92,11 @@ def test_depth_parity_chained_through_every_layer(model, dtype, early):
         final = {f"{k[0]}x{k[1]}": rel_l2(to_np64(hs[k]), hs64[k]) for k in hs}
         report[step_mode] = dict(first_layer=curve[0], worst=max(curve), final=final, layers=len(curve),
                                  every_8th=curve[7::8])
-        assert max(final.values()) < DEPTH_BOUND[model], (step_mode, final)
-        assert max(curve) < DEPTH_BOUND[model]
+        assert max(final.values()) < DEPTH_BOUND[(model, dtype)], (step_mode, final)
+        assert max(curve) < DEPTH_BOUND[(model, dtype)]
         # growth over depth stays far below linear accumulation of the per-layer error
         assert max(curve) < 0.5 * len(curve) * max(curve[0], 1e-4)
-    _record(f"depth_{model}", report)
+    _record(f"depth_{model}" + ("_fp16" if (model == "sdxl" and dtype == torch.float16) else ""), report)
 
 
 class OracleDenoiser(torch.nn.Module):

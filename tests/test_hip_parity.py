@@ -48,15 +48,21 @@ def test_gemm_nt_vs_fp64(dtype, mnk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
-@pytest.mark.parametrize("mnk,engine", [((33000, 512, 640), "pingpong256+tail128"),     # 258 big tiles: 256 + 2 cut in four
-                                        ((33001, 504, 640), "pingpong256+tail128"),     # ragged m and n edges
-                                        ((14336, 1280, 1280), "pingpong256+tail128"),   # SDXL out projection
-                                        ((3584, 3840, 1280), "pingpong256"),            # 210 tiles: one partial round
-                                        ((57344, 320, 320), "lockstep128"),             # short K loop
-                                        ((1000, 1280, 2048), "lockstep128")])           # too few tiles
-def test_gemm_engine_selection_and_parity(dtype, mnk, engine):
-    """Both k % 64 == 0 engines against fp64 on sampled rows (every row panel edge included), and the cost model
-    sends each shape to the engine the stack measurements favour (profiles/r01_gemm_variants.txt)."""
+@pytest.mark.parametrize("mnk,engine,tri", [((33000, 512, 640), "pingpong288", -1),           # 230 tiles of 288 rows: one round
+                                            ((33000, 512, 640), "pingpong256+tail128", 0),   # 258 big tiles: 256 + 2 cut in four
+                                            ((33001, 504, 640), "pingpong288", -1),           # ragged m and n edges
+                                            ((33001, 504, 640), "pingpong256+tail128", 0),
+                                            ((14336, 1280, 1280), "pingpong288", -1),         # SDXL out projection: 250 tiles
+                                            ((14336, 1280, 1280), "pingpong256+tail128", 0),
+                                            ((14336, 3840, 1280), "pingpong288", -1),         # 750 tiles = 2.93 rounds
+                                            ((3584, 3840, 1280), "pingpong256", -1),          # 210 tiles: one partial round
+                                            ((3584, 3840, 1280), "pingpong288", 1),           # forced: 13 row panels, the last 128 rows
+                                            ((57344, 320, 320), "lockstep128", -1),           # short K loop
+                                            ((1000, 1280, 2048), "lockstep128", -1)])         # too few tiles
+def test_gemm_engine_selection_and_parity(dtype, mnk, engine, tri, tuning):
+    """The k % 64 == 0 engines against fp64 on sampled rows (every row panel edge included), and the cost model
+    sends each shape to the engine the stack measurements favour (profiles/r01_gemm_variants.txt, profiles/r03_gemm_notes.txt)."""
+    tuning("GEMM_TRI", tri)
     m, n, k = mnk
     g = torch.Generator().manual_seed(m + n + k)
     a = torch.randn(m, k, generator=g).to(dtype)
@@ -65,6 +71,7 @@ def test_gemm_engine_selection_and_parity(dtype, mnk, engine):
     y = ops.linear(a.to(DEV), b.to(DEV), bias.to(DEV))
     assert ops.last_gemm_variant() == engine
     rows = torch.unique(torch.cat([torch.arange(0, m, 997), torch.arange(255, m, 256), torch.arange(256, m, 256),
+                                   torch.arange(287, m, 288), torch.arange(288, m, 288), torch.arange(256, m, 288),
                                    torch.tensor([m - 1])]))
     ref = to_np64(a[rows]) @ to_np64(b).T + to_np64(bias)
     assert rel_l2(to_np64(y[rows.to(DEV)]), ref) < TOL_GEMM[dtype]
@@ -74,7 +81,7 @@ def test_gemm_engine_selection_and_parity(dtype, mnk, engine):
     assert (col > 0.8).all() and (col < 1.25).all()
 
 
-def test_grouped_gemm_randomized_shapes_both_engines():
+def test_grouped_gemm_randomized_shapes_both_engines(tuning):
     """Seeded sweep over grouped launches (1-3 problems, batched operands, ragged m / n, equal and different K loops, both
     engines forced in turn where they apply) against fp32 torch matmuls of the same rounded operands on the GPU —
     a second, independent reference next to the fp64 oracle tests; catches tile-mapping mistakes at sizes the
@@ -87,6 +94,7 @@ def test_grouped_gemm_randomized_shapes_both_engines():
         nprob = int(rs.randint(1, 4))
         same_k = bool(rs.randint(0, 2)) or nprob == 1
         big = it % 3 == 0                                   # every third launch is large enough for the 256 x 256 engine
+        tuning("GEMM_TRI", [-1, 0, 1][(it // 3) % 3])       # big tiles of 256 rows / of 288 rows / the cost model's choice
         probs, refs = [], []
         for p in range(nprob):
             k = k_common if same_k else int(rs.choice([64, 192, 768, 2048]))
@@ -108,7 +116,7 @@ def test_grouped_gemm_randomized_shapes_both_engines():
             assert torch.isfinite(got).all(), (it, ops.last_gemm_variant())
             err = ((got - ref).norm() / ref.norm()).item()
             assert err < TOL_GEMM[dtype], (it, ops.last_gemm_variant(), p["m"], p["n"], p["k"], p["batch"], err)
-    assert {"lockstep128", "pingpong256"} <= {e.split("+")[0] for e in engines}, engines
+    assert {"lockstep128", "pingpong256", "pingpong288"} <= {e.split("+")[0] for e in engines}, engines
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
@@ -451,7 +459,7 @@ def test_full_size_processor_call_sdxl_level2(cross):
     proc = aid_amd.OuterInterpolatedAttnProcessor(size=n, is_fused=True, alpha=50, beta=50)
     proc.plain_tail = n
     y = proc(attn, x.to(DEV), encoder_hidden_states=None if ctx is None else ctx.to(DEV))
-    assert ops.last_gemm_variant().startswith("pingpong256")                    # the out projection, at least
+    assert ops.last_gemm_variant().startswith("pingpong2")                      # the out projection, at least (256- or 288-row tiles)
     w = O.AttnWeights(*(to_np64(t) for t in (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight,
                                               attn.to_out[0].weight, attn.to_out[0].bias)), heads)
     coef = to_np64(proc.coef.to(dtype))
@@ -899,7 +907,7 @@ def test_gemm_side_problems_ride_in_the_pingpong_launch(dtype):
                   stride_c=c * 8)]
     for group in (probs[:3], probs):
         ops.gemm_nt(group)
-        assert ops.last_gemm_variant().startswith("pingpong256") and ops.last_gemm_variant().endswith("side128"), \
+        assert ops.last_gemm_variant().startswith("pingpong2") and ops.last_gemm_variant().endswith("side128"), \
             ops.last_gemm_variant()
         rows = torch.tensor([0, 127, 128, 255, 256, 5000, n * s - 1])
         assert rel_l2(to_np64(q[rows]), to_np64(x[rows]) @ to_np64(wq).T) < TOL_GEMM[dtype]
