@@ -38,7 +38,7 @@ class AidGemmProblem(C.Structure):
         ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64),
         ("residual", C.c_void_p),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_shift", C.c_void_p),
-        ("ln_side", C.c_int32), ("reserved0", C.c_int32), ("stride_stats", C.c_int64),
+        ("ln_side", C.c_int32), ("trans_rows", C.c_int32), ("stride_stats", C.c_int64),
     ]
 
 

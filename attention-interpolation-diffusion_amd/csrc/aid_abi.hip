@@ -78,9 +78,14 @@ int check_problem(const AidGemmProblem& q) {
     if (!q.a || !q.b || !q.c) return AID_ERR_ARG;
     if (q.m < 0 || q.n < 0 || q.k <= 0 || q.batch < 1) return AID_ERR_ARG;
     if (q.k % 8 || q.lda % 8 || q.ldb % 8 || q.ldc % 4) return AID_ERR_SHAPE;
-    if (q.lda < q.k || q.ldb < q.k || q.ldc < round_up(q.n, 4)) return AID_ERR_SHAPE;
+    if (q.lda < q.k || q.ldb < q.k || (!q.trans_rows && q.ldc < round_up(q.n, 4))) return AID_ERR_SHAPE;
     if (!aligned16(q.a) || !aligned16(q.b) || !aligned16(q.c)) return AID_ERR_SHAPE;
     if ((q.stride_a % 8) || (q.stride_b % 8) || (q.stride_c % 4)) return AID_ERR_SHAPE;
+    if (q.trans_rows < 0) return AID_ERR_ARG;
+    if (q.trans_rows) {                                  // C transposed per frame (aid_hip.h)
+        if (q.batch != 1 || q.bias || q.residual || q.m % q.trans_rows || (q.ln_stats && q.ln_side != 1)) return AID_ERR_ARG;
+        if (q.trans_rows % 8 || q.ldc % 8 || q.ldc < q.trans_rows || q.stride_c % 8) return AID_ERR_SHAPE;
+    }
     return AID_OK;
 }
 
@@ -255,6 +260,7 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
         d.batch = q.batch;
         d.scale = q.scale == 0.f ? 1.f : q.scale;
         d.stride_a = q.stride_a; d.stride_b = q.stride_b; d.stride_c = q.stride_c;
+        d.trans_rows = q.trans_rows;
         if (q.ln_stats) {
             if (!q.ln_colsum || !q.ln_shift || (q.ln_side != 1 && q.ln_side != 2) || q.stride_stats < 0) return AID_ERR_ARG;
             d.ln_stats = q.ln_stats; d.ln_colsum = q.ln_colsum; d.ln_shift = q.ln_shift;
@@ -277,9 +283,10 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
         e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream), &g_gemm_variant);
         // profile entries carry the kernel SYMBOL that ran, so they line up with rocprofv3's per-kernel rows
         char nm[64];
-        const char* sym = !strncmp(g_gemm_variant, "pingpong", 8) ? "aid_gemm_nt_pp_kernel"
-                          : !strcmp(g_gemm_variant, "edge")      ? "aid_gemm_nt_kernel"
-                                                                 : "aid_gemm_nt_pipe_kernel";
+        const char* sym = !strncmp(g_gemm_variant, "pingpong288", 11) ? "aid_gemm_nt_ppx_kernel"
+                          : !strncmp(g_gemm_variant, "pingpong", 8)   ? "aid_gemm_nt_pp_kernel"
+                          : !strcmp(g_gemm_variant, "edge")           ? "aid_gemm_nt_kernel"
+                                                                      : "aid_gemm_nt_pipe_kernel";
         snprintf(nm, sizeof(nm), "%s<%s>", sym, dtype == AID_DTYPE_F16 ? "f16" : "bf16");
         ps.rename(nm);
     }
@@ -432,6 +439,15 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     pr[2].m = a.c; pr[2].n = l; pr[2].k = cc;
     pr[2].lda = cc; pr[2].ldb = cc; pr[2].ldc = cv.lp; pr[2].batch = nctx;
     pr[2].stride_a = 0; pr[2].stride_b = (int64_t)l * cc; pr[2].stride_c = (int64_t)a.c * cv.lp;
+    if (!cross && l % 8 == 0) {
+        // self-attention: the FLAT value projection x Wv^T with the transposed epilogue (AidGemmProblem.trans_rows) — the same
+        // V^T, but its tiles count like the q / k projections' (the 288-row engine then runs all three in whole CU rounds)
+        pr[2].a = e;    pr[2].b = a.wv;
+        pr[2].m = nctx * l; pr[2].n = a.c; pr[2].k = cc;
+        pr[2].lda = cc; pr[2].ldb = cc; pr[2].ldc = cv.lp; pr[2].batch = 1;
+        pr[2].stride_a = 0; pr[2].stride_b = 0; pr[2].stride_c = (int64_t)a.c * cv.lp;
+        pr[2].trans_rows = l;
+    }
     if (folded) {                                             // x W'^T with the LayerNorm applied in the epilogue
         pr[0].b = a.ln_wq;
         pr[0].ln_stats = stats; pr[0].ln_colsum = a.ln_const; pr[0].ln_shift = a.ln_const + a.c; pr[0].ln_side = 1;
@@ -439,9 +455,9 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
             pr[1].b = a.ln_wk;
             pr[1].ln_stats = stats; pr[1].ln_colsum = a.ln_const + 2 * a.c; pr[1].ln_shift = a.ln_const + 3 * a.c;
             pr[1].ln_side = 1;
-            pr[2].a = a.ln_wv;
             pr[2].ln_stats = stats; pr[2].ln_colsum = a.ln_const + 4 * a.c; pr[2].ln_shift = a.ln_const + 5 * a.c;
-            pr[2].ln_side = 2; pr[2].stride_stats = l;
+            if (pr[2].trans_rows) { pr[2].b = a.ln_wv; pr[2].ln_side = 1; }
+            else                  { pr[2].a = a.ln_wv; pr[2].ln_side = 2; pr[2].stride_stats = l; }
         }
     }
     int npr = 3;

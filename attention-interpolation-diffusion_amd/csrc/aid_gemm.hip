@@ -860,7 +860,10 @@ struct PingPongX : PingPong<T> {
     // The K loop of PingPong::mac_rd with the strip: stream per wave  B(0) A(0) X(0) B(1) | A(1) X(1) B(2) | A(2) X(2) B(3) ...
     //   READ-P0(kt): reads B0 B1 A0 of kt, requests A0 A1 X of kt + 1, retires A1(kt), X(kt)   (newer: B(kt+1) A(kt+1) X(kt+1))
     //   READ-P1(kt): reads A1(kt), X(kt), requests B0 B1 of kt + 2, retires B(kt+1), A0(kt+1)  (newer: A1(kt+1) X(kt+1) B(kt+2))
-    template <int WR>
+    // TR: the problem wants C transposed per frame (GemmDesc.trans_rows): the MFMAs are issued the other way round
+    // (D rows = m, columns = n), so a lane ends up with four consecutive ROWS of one output column and the staged tile
+    // can be written n-major with the same 8-byte stores.
+    template <int WR, bool TR>
     __device__ __forceinline__ void mac_x(int kb, int ke) {
         const int nk = ke - kb;
         const bool xw = wave < 4;
@@ -891,7 +894,7 @@ struct PingPongX : PingPong<T> {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ks = i >> 2, in = (i >> 1) & 1, e = i & 1;
-                acc[in][e] = mfma32(fb[in][ks], fa[e][ks], acc[in][e]);
+                acc[in][e] = TR ? mfma32(fa[e][ks], fb[in][ks], acc[in][e]) : mfma32(fb[in][ks], fa[e][ks], acc[in][e]);
             }
             PP::slot();
             this->read_a(fa, st, 1);
@@ -908,8 +911,9 @@ struct PingPongX : PingPong<T> {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ks = i >> 2, in = (i >> 1) & 1, e = i & 1;
-                acc[in][2 + e] = mfma32(fb[in][ks], fa[e][ks], acc[in][2 + e]);
-                if ((i & 3) == 3) accx = mfma32(fb[WR][ks], fx[ks], accx);      // the strip's block: this wave's own B fragment
+                acc[in][2 + e] = TR ? mfma32(fa[e][ks], fb[in][ks], acc[in][2 + e]) : mfma32(fb[in][ks], fa[e][ks], acc[in][2 + e]);
+                if ((i & 3) == 3)                                               // the strip's block: this wave's own B fragment
+                    accx = TR ? mfma32(fx[ks], fb[WR][ks], accx) : mfma32(fb[WR][ks], fx[ks], accx);
             }
             PP::slot();
         };
@@ -923,9 +927,92 @@ struct PingPongX : PingPong<T> {
         wait_vmcnt<0>();
         __syncthreads();                    // everyone is done reading the ring
     }
-    __device__ __forceinline__ void mac(int kb, int ke) {
-        if (wr == 0) mac_x<0>(kb, ke);      // two copies of the loop: fb[WR] must be a compile-time register choice
-        else         mac_x<1>(kb, ke);
+    // Whole tile: four copies of (K loop + epilogue) — fb[WR] must be a compile-time register choice and the operand order
+    // a compile-time choice; the epilogue sits INSIDE each copy so that no accumulator crosses a control-flow merge (with a
+    // common epilogue behind the four loops hipcc spilled 80 accumulator registers at the join).
+    __device__ __forceinline__ void run_tile(const GemmDesc& P, T* C, int batch, int m0, int n0) {
+        const int nk = P.k / 64;
+        const T* R = P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)batch * P.stride_c : nullptr;
+        const float* st = P.ln_stats ? P.ln_stats + 2 * (int64_t)batch * P.stride_stats : nullptr;
+        if (P.trans_rows) {
+            if (wr == 0) { mac_x<0, true>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
+            else         { mac_x<1, true>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
+        } else {
+            if (wr == 0) { mac_x<0, false>(0, nk); store_tile(P, C, m0, n0, R, st); }
+            else         { mac_x<1, false>(0, nk); store_tile(P, C, m0, n0, R, st); }
+        }
+    }
+
+    // Transposed epilogue (GemmDesc.trans_rows = rows per frame): element (m, n) goes to
+    //   C + (m / trans_rows) * stride_c + n * ldc + m % trans_rows      — V^T[frame][channel][key] from the FLAT product
+    // E W^T, so the value projection has the tile count of the q / k projections (SDXL: 250 tiles of 288 rows, not 280 of
+    // 256 channel rows) and one launch of all three is 750 tiles = 2.93 CU rounds.  Accumulators hold D rows = m.
+    __device__ __forceinline__ void store_tile_t(const GemmDesc& P, T* C, int m0, int n0, const float* stats) {
+        constexpr int NTHR = 512, BN = 256, CLDT = BMX + 8;
+        static_assert((size_t)BN * CLDT * 2 + LNS <= SMEMX, "transposed C tile fits");
+        T* Cs = reinterpret_cast<T*>(smem);        // [BN][CLDT]: n-major
+        mfma_fence(acc);
+        asm volatile("" : "+v"(accx));
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        asm volatile("" : "+v"(accx));
+        const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
+        const int side = stats ? P.ln_side : 0;    // 1 only (the activation is A): statistics per m, weight constants per n
+        float* const lnr = reinterpret_cast<float*>(smem + (size_t)BN * CLDT * 2);    // [BMX][2] row statistics
+        float* const lnc = lnr + 2 * BMX;                                             // [BN][2]  (colsum, shift)
+        if (side) {
+            for (int i = tid; i < BMX + BN; i += NTHR) {
+                const bool isrow = i < BMX;
+                const int gi = isrow ? min(m0 + i, P.m - 1) : min(n0 + i - BMX, P.n - 1);
+                lnr[2 * i] = isrow ? stats[2 * gi] : P.ln_colsum[gi];
+                lnr[2 * i + 1] = isrow ? stats[2 * gi + 1] : P.ln_shift[gi];
+            }
+            __syncthreads();
+        }
+        // one 32 x 32 block: column cb + l31, tile rows rb + 8 gq + 4 hi + e
+        auto stage = [&](const f32x16& a, int rb, int cb) __attribute__((always_inline)) {
+            const int col = cb + l31;
+            const float bv = (bias && n0 + col < P.n) ? (float)bias[n0 + col] : 0.f;
+            float cs = 0.f, sh = 0.f;
+            if (side) { cs = lnc[2 * col]; sh = lnc[2 * col + 1]; }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ml = rb + gq * 8 + hi * 4;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = a[gq * 4 + e];
+                if (side) {
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(lnr + 2 * ml);          // (mean, rstd) of rows ml, ml + 1
+                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(lnr + 2 * ml + 4);
+                    const float mu[4] = {p0[0], p0[2], p1[0], p1[2]}, rs[4] = {p0[1], p0[3], p1[1], p1[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = fmaf(-mu[e], cs, v[e]);
+                        asm volatile("" : "+v"(t));
+                        v[e] = fmaf(rs[e], t, sh);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], P.scale, bv);
+                *reinterpret_cast<T4*>(Cs + col * CLDT + ml) = cvt4<T>(v);
+            }
+        };
+#pragma unroll
+        for (int in = 0; in < 2; ++in)
+#pragma unroll
+            for (int im = 0; im < 4; ++im) stage(acc[in][im], wm + im * 32, wn + in * 32);
+        stage(accx, 256, wn + wr * 32);
+        __syncthreads();
+        constexpr int CPRW = BMX / 8;              // 16-B chunks (8 rows m) per staged n-row
+#pragma unroll
+        for (int it = 0; it < (BN * CPRW) / NTHR; ++it) {
+            const int id = tid + it * NTHR;
+            const int col = id / CPRW, ch = (id % CPRW) * 8;
+            const int m = m0 + ch, n = n0 + col;
+            if (m >= P.m || n >= P.n) continue;                  // trans_rows, m0 and P.m are multiples of 8: whole chunks
+            const int f = m / P.trans_rows, key = m - f * P.trans_rows;
+            *reinterpret_cast<T8*>(C + (int64_t)f * P.stride_c + (int64_t)n * P.ldc + key) =
+                *reinterpret_cast<const T8*>(Cs + col * CLDT + ch);
+        }
     }
 
     // Epilogue of Engine::store_tile for nine blocks per wave and 288 tile rows.
@@ -1030,7 +1117,7 @@ struct PingPongX : PingPong<T> {
         }
     }
 };
-static_assert((288 * 32) % 512 == 0, "C rows divide over the threads");
+static_assert((288 * 32) % 512 == 0 && (256 * 36) % 512 == 0, "C rows divide over the threads");
 static_assert(Engine<bf16, 128, 128, 64, 4, 2, 4>::SMEM <= PingPongX<bf16>::SMEMX, "side tiles use the big tile's LDS");
 
 template <typename T>
@@ -1071,9 +1158,7 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_ppx_kernel(const GemmGroup g,
     e.init(smem_raw);
     e.set_tile(P, A, B, tc.m0, tc.n0);
     e.zero_acc();
-    e.mac(0, P.k / 64);
-    e.store_tile(P, C, tc.m0, tc.n0, P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)tc.batch * P.stride_c : nullptr,
-                 P.ln_stats ? P.ln_stats + 2 * (int64_t)tc.batch * P.stride_stats : nullptr);
+    e.run_tile(P, C, tc.batch, tc.m0, tc.n0);
 }
 
 template <typename T, int PPV>
@@ -1299,12 +1384,54 @@ static bool prefer_ppx(GemmGroup& g, int ncu, const PpPlan& pl256) {
 // The big tiles win on long K loops and many tiles (SDXL C = 1280: 170 -> 145 us, 69 -> 58 us); the small ones on
 // short K loops (SD1.5 C = 320), on launches of less than half a round, and whenever the K loops of a group differ
 // (the text-context projections of cross-attention: their tiles are mostly padding at 256 x 256).
+// A problem with trans_rows (C transposed per frame, the flat value projection E Wv^T -> V^T) runs as such only on the
+// 288-row engine.  Everywhere else it is rewritten into the equivalent batched product with swapped operands,
+// V^T[f] = Wv E_f^T  (m' = n channels, n' = trans_rows keys, one batch entry per frame) — what the callers issued before.
+static bool has_trans(const GemmGroup& g) {
+    for (int i = 0; i < g.n_problems; ++i)
+        if (g.p[i].trans_rows) return true;
+    return false;
+}
+static void untranspose(GemmGroup& g) {
+    for (int i = 0; i < g.n_problems; ++i) {
+        GemmDesc& d = g.p[i];
+        if (!d.trans_rows) continue;
+        const int rows = d.trans_rows, frames = d.m / rows;
+        GemmDesc o = d;
+        o.a = d.b; o.b = d.a;
+        o.m = d.n; o.n = rows;
+        o.lda = d.ldb; o.ldb = d.lda;
+        o.batch = frames;
+        o.stride_a = 0; o.stride_b = (int64_t)rows * d.lda;      // stride_c = frame stride of V^T already
+        if (d.ln_stats) { o.ln_side = 2; o.stride_stats = rows; }
+        o.trans_rows = 0;
+        d = o;
+    }
+}
+
+template <typename T>
+static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char** variant, bool dry, bool* is_ppx);
+
 template <typename T>
 static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** variant) {
+    if (has_trans(g)) {
+        GemmGroup probe = g;
+        bool ppx = false;
+        const hipError_t e = launch_gemm_sel<T>(probe, stream, nullptr, true, &ppx);
+        if (e != hipSuccess) return e;
+        if (!ppx) untranspose(g);
+    }
+    return launch_gemm_sel<T>(g, stream, variant, false, nullptr);
+}
+
+// dry: pick the engine only (*is_ppx = the 288-row engine would run the main problems), launch nothing
+template <typename T>
+static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char** variant, bool dry, bool* is_ppx) {
     bool k64 = true;
     for (int i = 0; i < g.n_problems; ++i) k64 = k64 && (g.p[i].k % 64 == 0);
     if (!k64) {
         static PerDevice<bool> s0;
+        if (dry) return hipSuccess;
         if (variant) *variant = "edge";
         return launch_with_smem(aid_gemm_nt_kernel<T>, (size_t)2 * (GBM + GBN) * GLD * sizeof(T), &s0, g,
                                 plan_tiles(g, GBM, GBN), stream, GTHREADS);
@@ -1356,9 +1483,15 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** var
                 sd.tiles = st;
                 sd.pad_tiles = (st + 7) / 8 * 8;
                 if (prefer_ppx(gm, ncu, plm)) {
+                    if (dry) {                              // side tiles run on the 128 x 128 engine: no transposed output there
+                        *is_ppx = true;
+                        for (int i = 0; i < ns; ++i) *is_ppx = *is_ppx && !sd.p[i].trans_rows;
+                        return hipSuccess;
+                    }
                     if (variant) *variant = "pingpong288+side128";
                     return launch_ppx<T>(gm, stream, sd);
                 }
+                if (dry) return hipSuccess;
                 plan_pp(gm, ncu, nk);                       // back to 256 x 256 tile units
                 if (variant) *variant = plm.n_small ? "pingpong256+tail128+side128" : "pingpong256+side128";
                 return launch_pp<T>(gm, stream, plm, sd);
@@ -1378,9 +1511,11 @@ static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** var
     }
     if (force == 7) pp = false;
     if (pp && prefer_ppx(g, ncu, pl)) {
+        if (dry) { *is_ppx = true; return hipSuccess; }
         if (variant) *variant = "pingpong288";
         return launch_ppx<T>(g, stream, sd);
     }
+    if (dry) return hipSuccess;
     if (pp) plan_pp(g, ncu, g.p[0].k / 64);             // g.tile_start back in 256 x 256 units
     if (variant) *variant = !pp ? "lockstep128" : pl.n_small ? "pingpong256+tail128" : "pingpong256";
     if (pp) return launch_pp<T>(g, stream, pl, sd);

@@ -23,7 +23,7 @@ struct GemmDesc {
     const float* ln_colsum;                           // [weight rows]  sum_k W'[row, k]
     const float* ln_shift;                            // [weight rows]  sum_k beta[k] W[row, k]
     int32_t ln_side;                                  // 1: the activation is A (statistics by m), 2: it is B (by n)
-    int32_t reserved;
+    int32_t trans_rows;                               // > 0: C is written transposed per frame of `trans_rows` rows (AidGemmProblem)
     int64_t stride_stats;                             // activation rows per batch
 };
 

@@ -125,6 +125,7 @@ def gemm_nt(problems: Sequence[dict]) -> None:
         q.batch = p.get("batch", 1)
         q.scale = float(p.get("scale", 0.0))            # 0 = 1 (zero-initialised structs)
         q.stride_a, q.stride_b, q.stride_c = p.get("stride_a", 0), p.get("stride_b", 0), p.get("stride_c", 0)
+        q.trans_rows = int(p.get("trans_rows", 0))      # C transposed per frame of that many rows (aid_hip.h)
         if p.get("ln_stats") is not None:       # folded LayerNorm: dict(ln_stats=, ln_colsum=, ln_shift=, ln_side=1|2[, stride_stats=])
             for t_ in (p["ln_stats"], p["ln_colsum"], p["ln_shift"]):
                 _require_gpu(t_)
@@ -209,11 +210,11 @@ def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, extra_rows: 
     lp = (l + 7) // 8 * 8
     k = torch.empty(f + extra_rows, l, c, dtype=e.dtype, device=e.device)
     vt = torch.empty(f + extra_rows, c, lp, dtype=e.dtype, device=e.device)
-    gemm_nt([
-        dict(a=e, b=wk, c=k, m=f * l, n=c, k=cc, lda=cc, ldb=cc, ldc=c),
-        dict(a=wv, b=e, c=vt, m=c, n=l, k=cc, lda=cc, ldb=cc, ldc=lp, batch=f,
-             stride_a=0, stride_b=l * cc, stride_c=c * lp),
-    ])
+    if l % 8 == 0:          # flat value projection, transposed epilogue (tile count of the key projection: whole CU rounds)
+        pv = dict(a=e, b=wv, c=vt, m=f * l, n=c, k=cc, lda=cc, ldb=cc, ldc=lp, stride_c=c * lp, trans_rows=l)
+    else:                   # V^T[f] = Wv E_f^T, one batch entry per frame (pad columns l .. lp of V^T are written with zeros)
+        pv = dict(a=wv, b=e, c=vt, m=c, n=l, k=cc, lda=cc, ldb=cc, ldc=lp, batch=f, stride_a=0, stride_b=l * cc, stride_c=c * lp)
+    gemm_nt([dict(a=e, b=wk, c=k, m=f * l, n=c, k=cc, lda=cc, ldb=cc, ldc=c), pv])
     return k, vt
 
 

@@ -96,7 +96,13 @@ typedef struct AidGemmProblem {
     const float* ln_colsum;
     const float* ln_shift;
     int32_t      ln_side;
-    int32_t      reserved0;
+    /* trans_rows > 0: C is written TRANSPOSED per frame of `trans_rows` rows: element (row m, column j) goes to          */
+    /*     c + (m / trans_rows) * stride_c + j * ldc + m % trans_rows                                                     */
+    /* i.e. V^T[frame][channel][key] from the flat value projection  E Wv^T  (a = E [frames * keys, k], b = Wv [n, k]),    */
+    /* the layout the attention core reads.  Requirements: batch == 1, m % trans_rows == 0, trans_rows % 8 == 0,          */
+    /* ldc >= trans_rows, ldc % 8 == 0, stride_c % 8 == 0, no bias, no residual, ln_side 1 if LayerNorm is folded.         */
+    /* (Same numbers as the batched form  V^T[f] = Wv E_f^T; the library picks whichever its tile engines run faster.)    */
+    int32_t      trans_rows;
     int64_t      stride_stats;
 } AidGemmProblem;
 

@@ -916,3 +916,48 @@ def test_gemm_side_problems_ride_in_the_pingpong_launch(dtype):
         assert rel_l2(to_np64(vt[:, :, :l]), ref_vt) < TOL_GEMM[dtype] and float(vt[:, :, l:].abs().max()) == 0.0
     assert rel_l2(to_np64(kip), to_np64(ip) @ to_np64(wki).T) < TOL_GEMM[dtype]
     assert rel_l2(to_np64(vtip[:, :, :t_ip]), np.einsum("ck,ftk->fct", to_np64(wvi), to_np64(ip))) < TOL_GEMM[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("tri,frames,keys,c,k", [(1, 14, 1024, 1280, 1280),      # SDXL level 2: flat value projection on the 288-row engine
+                                                 (-1, 14, 1024, 1280, 1280),     # the cost model's choice for the same launch
+                                                 (0, 14, 1024, 1280, 1280),      # rewritten into the batched form, 256-row tiles
+                                                 (1, 5, 1000, 640, 320),         # ragged: 5000 rows, last tile 104 rows; 2.5 column tiles
+                                                 (-1, 3, 200, 128, 64)])         # small: lock-step engine, batched form
+def test_gemm_transposed_per_frame_output(dtype, tri, frames, keys, c, k, tuning):
+    """AidGemmProblem.trans_rows: the flat value projection E Wv^T written as V^T[frame][channel][key] — grouped with a q- and a
+    k-shaped problem like the processor call issues it — equals the batched form V^T[f] = Wv E_f^T bit for bit and fp64 within
+    the GEMM tolerance, whichever engine runs it; with and without the folded LayerNorm."""
+    tuning("GEMM_TRI", tri)
+    g = torch.Generator().manual_seed(frames * 31 + keys)
+    e = (torch.randn(frames * keys, k, generator=g) + 0.7).to(dtype).to(DEV)
+    wq, wk, wv = ((torch.randn(c, k, generator=g) / k ** 0.5).to(dtype).to(DEV) for _ in range(3))
+    q, kk = (torch.empty(frames * keys, c, dtype=dtype, device=DEV) for _ in range(2))
+    vt = torch.full((frames, c, keys), float("nan"), dtype=dtype, device=DEV)
+    ops.gemm_nt([dict(a=e, b=wq, c=q, m=frames * keys, n=c, k=k, lda=k, ldb=k, ldc=c),
+                 dict(a=e, b=wk, c=kk, m=frames * keys, n=c, k=k, lda=k, ldb=k, ldc=c),
+                 dict(a=e, b=wv, c=vt, m=frames * keys, n=c, k=k, lda=k, ldb=k, ldc=keys, stride_c=c * keys, trans_rows=keys)])
+    name = ops.last_gemm_variant()
+    if tri == 1 and k >= 1280:                                        # (short K loops stay on the lock-step engine)
+        assert name == "pingpong288", name
+    ref = np.einsum("ck,flk->fcl", to_np64(wv), to_np64(e).reshape(frames, keys, k))
+    assert torch.isfinite(vt).all(), name
+    assert rel_l2(to_np64(vt), ref) < TOL_GEMM[dtype] and worst(to_np64(vt), ref) < WORST[dtype], name
+    assert rel_l2(to_np64(kk), to_np64(e) @ to_np64(wk).T) < TOL_GEMM[dtype]
+    vb = torch.empty_like(vt)
+    tuning("GEMM_TRI", 0)
+    ops.gemm_nt([dict(a=wv, b=e, c=vb, m=c, n=keys, k=k, lda=k, ldb=k, ldc=keys, batch=frames, stride_a=0, stride_b=keys * k,
+                      stride_c=c * keys)])
+    assert torch.equal(vt, vb), name                                  # same products, same summation order: bitwise
+    # folded LayerNorm on the flat form (the activation is operand A: statistics by output row)
+    if k % 64 == 0:
+        tuning("GEMM_TRI", tri)
+        gamma, beta = (torch.randn(k, generator=g) * 0.3 + 1).to(dtype).to(DEV), (torch.randn(k, generator=g) * 0.2).to(dtype).to(DEV)
+        wf, cs, sh = ops.ln_fold(wv, gamma, beta)
+        stats = ops.ln_stats(e)
+        vl = torch.empty_like(vt)
+        ops.gemm_nt([dict(a=e, b=wf, c=vl, m=frames * keys, n=c, k=k, lda=k, ldb=k, ldc=keys, stride_c=c * keys, trans_rows=keys,
+                          ln_stats=stats, ln_colsum=cs, ln_shift=sh, ln_side=1)])
+        xn = O.layer_norm(to_np64(e), to_np64(gamma), to_np64(beta), 1e-5).reshape(frames, keys, k)
+        refl = np.einsum("ck,flk->fcl", to_np64(wv), xn)
+        assert rel_l2(to_np64(vl), refl) < 2 * TOL_GEMM[dtype], (name, ops.last_gemm_variant())
