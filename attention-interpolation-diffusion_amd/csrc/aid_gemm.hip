@@ -258,6 +258,105 @@ __global__ __launch_bounds__(GTHREADS) void aid_gemm_nt_kernel(const GemmGroup g
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast epilogue (tile columns inside the matrix, 16-byte aligned rows / pointers): straight-line code.
+// The generic epilogue below handles every edge (ragged n, unaligned bias / residual, odd ldc) with per-element guards;
+// compiled for a full tile it still carried ~250 exec-mask branches, scalar loads inside the staging loop (each one a full
+// lgkmcnt wait = every LDS write drained) and one LDS round trip per global store: 10 us of a 55 us out-projection launch
+// next to 6.5 us of actual HBM write time (profiles/r03_gemm_notes.txt).  Here every uniform decision is taken once per
+// tile, the bias / LayerNorm constants of a column block are fetched once, and the global side is `store_rows_fast`.
+// ------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+
+// one 32 x 32 accumulator block of the n-major MFMA issue: lane (l31, hi) holds row `row`, columns nl0 + 8 gq + e
+template <typename T, int SIDE>
+__device__ __forceinline__ void stage_block_fast(T* Cs, int cld, const f32x16& a, int row, int nl0, float scale, const f32x4 (&bv)[4],
+                                                 const float* lnr, const float* lnc) {
+    typedef typename Vec<T>::v4 T4;
+    float lr0 = 0.f, lr1 = 0.f;
+    if (SIDE) { lr0 = lnr[2 * row]; lr1 = lnr[2 * row + 1]; }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int nl = nl0 + gq * 8;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a[gq * 4 + e];
+        if (SIDE) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(lnc + 2 * nl);          // (c0, c1) of columns nl, nl + 1
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(lnc + 2 * nl + 4);      // nl + 2, nl + 3
+            const float c0[4] = {p0[0], p0[2], p1[0], p1[2]}, c1[4] = {p0[1], p0[3], p1[1], p1[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {               // scalar FMAs on purpose, see Engine::store_tile
+                float t = SIDE == 1 ? fmaf(-lr0, c0[e], v[e]) : fmaf(-c0[e], lr0, v[e]);
+                asm volatile("" : "+v"(t));
+                v[e] = SIDE == 1 ? fmaf(lr1, t, c1[e]) : fmaf(c1[e], t, lr1);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = fmaf(v[e], scale, bv[gq][e]);
+            asm volatile("" : "+v"(t));                 // keeps hipcc from pairing them into v_pk_fma_f32 (slower beside nothing, and see above)
+            v[e] = t;
+        }
+        *reinterpret_cast<T4*>(Cs + row * cld + nl) = cvt4<T>(v);
+    }
+}
+
+// bias of the 16 columns a lane owns in one 32-column block (columns nl0 + 8 gq + e), fp32; zero without a bias
+template <typename T>
+__device__ __forceinline__ void bias_block(f32x4 (&bv)[4], const T* bias, int ncol0) {
+    typedef typename Vec<T>::v4 T4;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        if (bias) bv[gq] = up4<T>(*reinterpret_cast<const T4*>(bias + ncol0 + gq * 8));
+        else      bv[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// LDS C tile [ROWS][CLD] -> global rows, 16 B per lane: all LDS reads of the pass group issued before the first store, store
+// addresses = one 32-bit per-thread offset + a scalar pass offset.  R (optional): residual, added after the rounding.
+template <typename T, int NTHR, int ROWS, int BN, int CLD>
+__device__ __forceinline__ void store_rows_fast(const T* Cs, T* C, const T* R, int m0, int n0, int ldc, int rows_valid, int tid) {
+    typedef typename Vec<T>::v8 T8;
+    constexpr int CPRW = BN / 8, RPP = NTHR / CPRW, NP = ROWS / RPP;      // chunks per row, rows per pass, passes
+    static_assert(NTHR % CPRW == 0 && ROWS % RPP == 0, "rows divide over the passes");
+    constexpr int G = NP % 9 == 0 ? 9 : (NP % 8 == 0 ? 8 : (NP % 4 == 0 ? 4 : 1));     // passes in flight together
+    const int r0 = tid / CPRW, ch = (tid % CPRW) * 8;
+    // (the scalar offset is not part of the descriptor's range check: rows past the matrix are predicated, not "dropped")
+    const BufRsrc rc = __builtin_amdgcn_make_buffer_rsrc(C + (int64_t)m0 * ldc + n0, 0, 0x7fffffff, 0x00020000);
+    const BufRsrc rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(R ? R : C) + (int64_t)m0 * ldc + n0, 0, 0x7fffffff, 0x00020000);
+    const int voff = (r0 * ldc + ch) * 2;
+    const int pass = RPP * ldc * 2;                     // bytes between passes (scalar)
+    const T* src = Cs + r0 * CLD + ch;
+#pragma unroll
+    for (int g0 = 0; g0 < NP; g0 += G) {
+        T8 v[G], r[G];
+        if (R) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                r[i] = (r0 + RPP * (g0 + i) < rows_valid)
+                           ? __builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(rr, voff, (g0 + i) * pass, 0)) : zero8<T>();
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) v[i] = *reinterpret_cast<const T8*>(src + (g0 + i) * RPP * CLD);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            T8 o = v[i];
+            if (R) o = cvt8<T>(up8<T>(v[i]) + up8<T>(r[i]));
+            if (r0 + RPP * (g0 + i) < rows_valid)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, voff, (g0 + i) * pass, 0);
+        }
+    }
+}
+
+// may this tile take the fast epilogue?
+template <typename T>
+__device__ __forceinline__ bool epilogue_fast_ok(const GemmDesc& P, const T* C, const T* R, int n0, int bn) {
+    return n0 + bn <= P.n && P.ldc % 8 == 0 && P.ldc < (1 << 20) && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(P.bias) & 7) == 0 && (!R || (reinterpret_cast<uintptr_t>(R) & 15) == 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // main path: NS-stage LDS-DMA ring
 //   row bytes RB = 2*BK; a 16-B chunk c of tile row r is stored at chunk slot c ^ swz(r) with
@@ -404,6 +503,20 @@ struct Engine {
         __syncthreads();                       // everyone is done reading the ring
     }
 
+    template <int SIDE>
+    __device__ __forceinline__ void stage_all_fast(const GemmDesc& P, T* Cs, int n0, const float* lnr, const float* lnc) {
+        const T* bias = reinterpret_cast<const T*>(P.bias);
+        const float scale = P.scale;
+#pragma unroll
+        for (int in = 0; in < NB; ++in) {
+            f32x4 bv[4];
+            bias_block<T>(bv, bias, n0 + wn + in * 32 + hi * 4);
+#pragma unroll
+            for (int im = 0; im < MB; ++im)
+                stage_block_fast<T, SIDE>(Cs, CLD, acc[in][im], wm + im * 32 + l31, wn + in * 32 + hi * 4, scale, bv, lnr, lnc);
+        }
+    }
+
     // acc (+bias) -> LDS C tile -> coalesced 16-B row segments.  Ends with all stores drained and a barrier.
     // `R` (optional, laid out like C) is added after the rounding to T — the transformer block's residual add.
     __device__ __forceinline__ void store_tile(const GemmDesc& P, T* C, int m0, int n0, const T* R = nullptr,
@@ -412,6 +525,27 @@ struct Engine {
         mfma_fence(acc);
         const T* __restrict__ bias = reinterpret_cast<const T*>(P.bias);
         const bool bias_vec = (reinterpret_cast<uintptr_t>(bias) & 7) == 0;
+        if (epilogue_fast_ok<T>(P, C, R, n0, BN)) {             // straight-line epilogue (see stage_block_fast)
+            const int side_f = stats ? P.ln_side : 0;
+            float* const lnr_f = reinterpret_cast<float*>(smem + (size_t)BM * CLD * 2);
+            float* const lnc_f = lnr_f + 2 * BM;
+            if (side_f) {
+                for (int i = tid; i < BM + BN; i += NTHR) {
+                    const bool isrow = i < BM;
+                    const int gi = isrow ? min(m0 + i, P.m - 1) : n0 + i - BM;
+                    const bool st = isrow == (side_f == 1);
+                    lnr_f[2 * i] = st ? stats[2 * gi] : P.ln_colsum[gi];
+                    lnr_f[2 * i + 1] = st ? stats[2 * gi + 1] : P.ln_shift[gi];
+                }
+                __syncthreads();
+            }
+            if (side_f == 0)      stage_all_fast<0>(P, Cs, n0, lnr_f, lnc_f);
+            else if (side_f == 1) stage_all_fast<1>(P, Cs, n0, lnr_f, lnc_f);
+            else                  stage_all_fast<2>(P, Cs, n0, lnr_f, lnc_f);
+            __syncthreads();
+            store_rows_fast<T, NTHR, BM, BN, CLD>(Cs, C, R, m0, n0, P.ldc, min(BM, P.m - m0), tid);
+            return;
+        }
         // folded LayerNorm: the tile's per-row and per-column pairs go through LDS (behind the C tile) — one coalesced load
         // per thread instead of 8 broadcast loads per 4-column group; ln_side 1: rows carry (mean, rstd), columns
         // (colsum, shift); ln_side 2: the other way round
@@ -814,6 +948,7 @@ struct PingPongX : PingPong<T> {
     using PP::ra; using PP::rb; using PP::avo; using PP::bvo;
     f32x16 accx;
     int xoff, xx, xvo;
+    int abl_ = 0;               // development builds: 4 = epilogue without the global stores, 8 = without the staging pass
 
     __device__ __forceinline__ void init(char* smem_) {
         PP::init(smem_);
@@ -930,16 +1065,26 @@ struct PingPongX : PingPong<T> {
     // Whole tile: four copies of (K loop + epilogue) — fb[WR] must be a compile-time register choice and the operand order
     // a compile-time choice; the epilogue sits INSIDE each copy so that no accumulator crosses a control-flow merge (with a
     // common epilogue behind the four loops hipcc spilled 80 accumulator registers at the join).
-    __device__ __forceinline__ void run_tile(const GemmDesc& P, T* C, int batch, int m0, int n0) {
+    __device__ __forceinline__ void run_tile(const GemmDesc& P, T* C, int batch, int m0, int n0, int abl = 0) {
         const int nk = P.k / 64;
+        abl_ = abl;
         const T* R = P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)batch * P.stride_c : nullptr;
         const float* st = P.ln_stats ? P.ln_stats + 2 * (int64_t)batch * P.stride_stats : nullptr;
         if (P.trans_rows) {
             if (wr == 0) { mac_x<0, true>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
             else         { mac_x<1, true>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
         } else {
-            if (wr == 0) { mac_x<0, false>(0, nk); store_tile(P, C, m0, n0, R, st); }
-            else         { mac_x<1, false>(0, nk); store_tile(P, C, m0, n0, R, st); }
+            // (abl: timing ablations of development builds — 1 = no epilogue, 2 = no K loop; one call site per instantiation:
+            //  a second `mac_x<1, false>` call elsewhere fails to instantiate in hipcc's host pass)
+            if (wr == 0) { if (!(abl & 2)) mac_x<0, false>(0, nk); if (!(abl & 1)) store_tile(P, C, m0, n0, R, st); }
+            else         { if (!(abl & 2)) mac_x<1, false>(0, nk); if (!(abl & 1)) store_tile(P, C, m0, n0, R, st); }
+            if (abl & 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+                asm volatile("" ::"v"(accx));
+            }
         }
     }
 
@@ -1002,6 +1147,28 @@ struct PingPongX : PingPong<T> {
             for (int im = 0; im < 4; ++im) stage(acc[in][im], wm + im * 32, wn + in * 32);
         stage(accx, 256, wn + wr * 32);
         __syncthreads();
+        // Fast path: frames at least as long as the tile (the tile touches at most two frames: one compare instead of a division
+        // per chunk), all 18 LDS reads up front, then the stores.  Thread -> (staged row `col` = id / 36, chunk of 8 keys).
+        if (P.trans_rows >= BMX && n0 + BN <= P.n && ((reinterpret_cast<uintptr_t>(C) & 15) == 0)) {
+            const int f0 = m0 / P.trans_rows;                       // scalar
+            const int next = (f0 + 1) * P.trans_rows - m0;          // first tile row of the next frame
+            constexpr int NPT = (BN * (BMX / 8)) / NTHR;            // 18
+            T8 v[NPT];
+            T* dst[NPT];
+#pragma unroll
+            for (int it = 0; it < NPT; ++it) {
+                const int id = tid + it * NTHR;
+                const int col = id / (BMX / 8), chm = (id % (BMX / 8)) * 8;
+                v[it] = *reinterpret_cast<const T8*>(Cs + col * CLDT + chm);
+                const int f = f0 + (chm >= next ? 1 : 0);
+                dst[it] = (m0 + chm < P.m) ? C + (int64_t)f * P.stride_c + (int64_t)(n0 + col) * P.ldc + (m0 + chm - f * P.trans_rows)
+                                           : nullptr;
+            }
+#pragma unroll
+            for (int it = 0; it < NPT; ++it)
+                if (dst[it]) *reinterpret_cast<T8*>(dst[it]) = v[it];
+            return;
+        }
         constexpr int CPRW = BMX / 8;              // 16-B chunks (8 rows m) per staged n-row
 #pragma unroll
         for (int it = 0; it < (BN * CPRW) / NTHR; ++it) {
@@ -1013,6 +1180,23 @@ struct PingPongX : PingPong<T> {
             *reinterpret_cast<T8*>(C + (int64_t)f * P.stride_c + (int64_t)n * P.ldc + key) =
                 *reinterpret_cast<const T8*>(Cs + col * CLDT + ch);
         }
+    }
+
+    template <int SIDE>
+    __device__ __forceinline__ void stage_x_fast(const GemmDesc& P, T* Cs, int n0, const float* lnr, const float* lnc) {
+        const T* bias = reinterpret_cast<const T*>(P.bias);
+        const float scale = P.scale;
+        f32x4 bvx[4];
+#pragma unroll
+        for (int in = 0; in < 2; ++in) {
+            f32x4 bv[4];
+            bias_block<T>(bv, bias, n0 + wn + in * 32 + hi * 4);
+#pragma unroll
+            for (int im = 0; im < 4; ++im)
+                stage_block_fast<T, SIDE>(Cs, CLD, acc[in][im], wm + im * 32 + l31, wn + in * 32 + hi * 4, scale, bv, lnr, lnc);
+        }
+        bias_block<T>(bvx, bias, n0 + wn + wr * 32 + hi * 4);                    // the strip's block: columns of B fragment wr
+        stage_block_fast<T, SIDE>(Cs, CLD, accx, 256 + l31, wn + wr * 32 + hi * 4, scale, bvx, lnr, lnc);
     }
 
     // Epilogue of Engine::store_tile for nine blocks per wave and 288 tile rows.
@@ -1029,6 +1213,28 @@ struct PingPongX : PingPong<T> {
         const int side = stats ? P.ln_side : 0;
         float* const lnr = reinterpret_cast<float*>(smem + (size_t)BMX * CLD * 2);    // [BMX][2]
         float* const lnc = lnr + 2 * BMX;                                             // [BN][2]
+        if (epilogue_fast_ok<T>(P, C, R, n0, BN)
+#ifdef AID_ABLATIONS
+            && !(abl_ & 12)
+#endif
+        ) {                                                     // straight-line epilogue (see stage_block_fast)
+            if (side) {
+                for (int i = tid; i < BMX + BN; i += NTHR) {
+                    const bool isrow = i < BMX;
+                    const int gi = isrow ? min(m0 + i, P.m - 1) : n0 + i - BMX;
+                    const bool st = isrow == (side == 1);
+                    lnr[2 * i] = st ? stats[2 * gi] : P.ln_colsum[gi];
+                    lnr[2 * i + 1] = st ? stats[2 * gi + 1] : P.ln_shift[gi];
+                }
+                __syncthreads();
+            }
+            if (side == 0)      stage_x_fast<0>(P, Cs, n0, lnr, lnc);
+            else if (side == 1) stage_x_fast<1>(P, Cs, n0, lnr, lnc);
+            else                stage_x_fast<2>(P, Cs, n0, lnr, lnc);
+            __syncthreads();
+            store_rows_fast<T, NTHR, BMX, BN, CLD>(Cs, C, R, m0, n0, P.ldc, min(BMX, P.m - m0), tid);
+            return;
+        }
         if (side) {
             for (int i = tid; i < BMX + BN; i += NTHR) {
                 const bool isrow = i < BMX;
@@ -1078,11 +1284,26 @@ struct PingPongX : PingPong<T> {
                 *reinterpret_cast<T4*>(Cs + row * CLD + nl) = cvt4<T>(v);
             }
         };
+#ifdef AID_ABLATIONS
+        if (!(abl_ & 8))
+#endif
+        {
 #pragma unroll
         for (int in = 0; in < 2; ++in)
 #pragma unroll
             for (int im = 0; im < 4; ++im) stage(acc[in][im], wm + im * 32, wn + in * 32);
         stage(accx, 256, wn + wr * 32);
+        }
+#ifdef AID_ABLATIONS
+        if (abl_ & 8) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) asm volatile("" ::"v"(acc[i][jj]));
+            asm volatile("" ::"v"(accx));
+        }
+        if (abl_ & 4) return;
+#endif
         __syncthreads();
         const bool vec_ok = (P.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
         constexpr int CPRW = BN / 8;               // 16-B chunks per C row
@@ -1121,7 +1342,7 @@ static_assert((288 * 32) % 512 == 0 && (256 * 36) % 512 == 0, "C rows divide ove
 static_assert(Engine<bf16, 128, 128, 64, 4, 2, 4>::SMEM <= PingPongX<bf16>::SMEMX, "side tiles use the big tile's LDS");
 
 template <typename T>
-__global__ __launch_bounds__(512) void aid_gemm_nt_ppx_kernel(const GemmGroup g, const GemmSide sd) {
+__global__ __launch_bounds__(512) void aid_gemm_nt_ppx_kernel(const GemmGroup g, const GemmSide sd, const int abl) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if ((int)blockIdx.x < sd.pad_tiles) {                          // side problems first (see aid_gemm_nt_pp_kernel)
         const int u = blockIdx.x;
@@ -1158,7 +1379,11 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_ppx_kernel(const GemmGroup g,
     e.init(smem_raw);
     e.set_tile(P, A, B, tc.m0, tc.n0);
     e.zero_acc();
+#ifdef AID_ABLATIONS
+    e.run_tile(P, C, tc.batch, tc.m0, tc.n0, abl);
+#else
     e.run_tile(P, C, tc.batch, tc.m0, tc.n0);
+#endif
 }
 
 template <typename T, int PPV>
@@ -1360,7 +1585,8 @@ static hipError_t launch_ppx(GemmGroup& g, hipStream_t stream, const GemmSide& s
         if (e != hipSuccess) return e;
         *done = true;
     }
-    hipLaunchKernelGGL(aid_gemm_nt_ppx_kernel<T>, dim3(sd.pad_tiles + tiles), dim3(512), PingPongX<T>::SMEMX, stream, g, sd);
+    const int abl = tune(TUNE_GEMM_PP) >= 8 ? tune(TUNE_GEMM_PP) - 8 : 0;     // development builds only (AID_ABLATIONS)
+    hipLaunchKernelGGL(aid_gemm_nt_ppx_kernel<T>, dim3(sd.pad_tiles + tiles), dim3(512), PingPongX<T>::SMEMX, stream, g, sd, abl);
     return hipGetLastError();
 }
 
