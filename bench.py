@@ -125,10 +125,10 @@ def make_inputs(unet, n_frames, dtype, device, seed=1002, n_ctx=None):
 
 
 def recorded_traffic(stack, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC collection (profiles/r02_pmc.json, written by
+    """HBM bytes per launch of `kernel` from the committed PMC collection (profiles/r03_pmc.json, written by
     tools/pmc_collect.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, gfx950 x2
     correction on FETCH_SIZE applied).  PMC counters cannot be collected from inside this process; null if absent."""
-    for name in ("r02_pmc.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["models"][stack][kernel]["hbm_bytes_per_launch"]

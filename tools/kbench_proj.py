@@ -21,7 +21,7 @@ for tag, dt, s, c in (("sd15 L0", torch.float16, 4096, 320), ("sd15 L1", torch.f
     def qkv():
         ops.gemm_nt([dict(a=x, b=wq, c=q, m=n * s, n=c, k=c, lda=c, ldb=c, ldc=c),
                      dict(a=x, b=wk, c=k, m=n * s, n=c, k=c, lda=c, ldb=c, ldc=c),
-                     dict(a=wv, b=x, c=vt, m=c, n=s, k=c, lda=c, ldb=c, ldc=s, batch=n, stride_a=0, stride_b=s * c, stride_c=c * s)])
+                     dict(a=x, b=wv, c=vt, m=n * s, n=c, k=c, lda=c, ldb=c, ldc=s, stride_c=c * s, trans_rows=s)])      # as aid_processor_fwd issues it
     us, fl = timed(qkv); print(f"{tag} qkv  M={n*s} C={c}: {us:7.1f} us {fl/us/1e6:7.1f} TF/s  ideal-HBM {(4*n*s*c*2 + 3*c*c*2)/5e6:6.1f} us")
     us, fl = timed(lambda: ops.linear(x, wo, bo, out=y)); print(f"{tag} out  M={n*s} C={c}: {us:7.1f} us {fl/us/1e6:7.1f} TF/s  ideal-HBM {(2*n*s*c*2)/5e6:6.1f} us")
 
