@@ -1,0 +1,311 @@
+// Ping-pong attention core for head dim 64 and ONE key segment per frame — plain attention (de-activated passes, reference
+// interpolation.py:581-584), the PLAIN rider frames of a batched-CFG call and the fused END-POINT frames of an INNER / OUTER call
+// (their second segment would be their own keys again, see aid_attn.hip).  Same arithmetic as aid_attn_kernel (swapped
+// products, softmax arithmetic in the matrix pipe, lazy row reference); what differs is WHO does what WHEN:
+//
+//   One workgroup = 8 waves x 32 query rows of one (frame, head); waves w and w + 4 share a SIMD.  Waves 0-3 and waves 4-7
+//   run the same program ONE BARRIER APART, and the program alternates two slots per 64-key tile:
+//     M(t)   every MFMA of the tile in one burst: S(t) = K(t) Q'^T - m (8) and O^T += V^T(t-1) P(t-1)^T (12), operand
+//            fragments read from LDS two steps ahead — nothing else
+//     V(t)   the VALU half: head-room check, P(t) = 2^S(t), rounding to the storage type; plus this wave's two LDS-DMA
+//            pieces of a tile further down the stream and the counted wait that publishes an earlier one
+//   so while one wave of a SIMD keeps the matrix pipe busy its partner does the exponentials, and vice versa.  In the
+//   program-order kernel the three co-resident waves of a SIMD drift into the same phase and MFMA time and VALU time add up
+//   (1100 cycles per wave-tile for 640 of MFMA, profiles/r02_attn_notes.txt); here they are complementary by construction.
+//   K / V^T tiles go HBM -> LDS by DMA (no staging registers, no ds_write pass) into a ring of four 16 KB stages; rows are
+//   unpadded 128 B, bank conflicts are avoided by the XOR swizzle of the GEMM (on the DMA source address and on the read).
+//
+// Schedule (interval = the time between two workgroup barriers; group g = wave / 4 executes slot s of its program in interval
+// s + g):  M(t) in interval 2t + g, V(t) in 2t + 1 + g.  Tile t sits in ring stage t & 3 and is read in M(t) (K) and M(t+1) (V^T)
+// of both groups, i.e. through interval 2t + 3; a wave requests its pieces of tile j + 2 + g in V(j) (interval >= 2(j+2+g-4) + 4,
+// the first interval in which stage (j+2+g) & 3 is free) and retires with vmcnt(2), which leaves only the two just issued in
+// flight — every piece of tile T is then landed AND barrier-published before interval 2T, when group 0 reads K(T).
+#include <type_traits>
+
+#include "aid_common.hpp"
+#include "aid_kernels.hpp"
+
+namespace aid {
+
+namespace {
+
+constexpr int PKT = 64;                 // keys per tile
+constexpr int PSTAGE = 16384;           // bytes per ring stage: K tile [64 keys][128 B] + V^T tile [64 rows][128 B]
+constexpr int PNS = 4;                  // ring depth
+
+struct AttnPPParams {
+    AidAttnArgs a;
+    int32_t nqb;                        // 256-row q blocks per (frame, head)
+    int32_t n_list;                     // frames this launch runs
+    float   c2;                         // softmax_scale * log2(e)
+    int32_t frames[32];                 // their indices in the caller's batch
+};
+
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void slot_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) {
+    typedef typename Vec<T>::v8 T8;
+    typedef typename Vec<T>::v4 T4;
+    constexpr int D = 64;
+    constexpr float XTH = std::is_same<T, f16>::value ? 15.0f : 60.0f;      // head-room (log2) of P = 2^x in the storage type
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const AidAttnArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);           // [head][frame][q block]: a (frame, head)'s blocks share an L2
+    const int qb = lid % p.nqb;
+    const int fr = p.frames[(lid / p.nqb) % p.n_list];
+    const int h = lid / (p.nqb * p.n_list);
+    const int q0 = (qb * 8 + wave) * 32;
+    const int kvf = a.kv_map ? a.kv_map[fr] : fr;
+
+    // ---- Q fragments (B operand of the swapped product) -----------------------------------------
+    T8 qf[4];
+    {
+        const int qr = min(q0 + l31, a.s - 1);                  // rows past the end are clamped, never stored
+        const T* qrow = reinterpret_cast<const T*>(a.q) + (int64_t)fr * a.q_fs + (int64_t)qr * a.ldq + h * D;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const T8*>(qrow + ks * 16 + hi * 8);
+            if (!a.q_prescaled) {
+                f32x8 t = up8<T>(qf[ks]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] *= p.c2;
+                qf[ks] = cvt8<T>(t);
+            }
+        }
+    }
+    T8 onesf;                                                   // A fragment of the row-sum block: row 0 = ones
+#pragma unroll
+    for (int e = 0; e < 8; ++e) onesf[e] = (l31 == 0) ? (T)1.0f : (T)0.0f;
+
+    // ---- DMA addressing: this wave's piece (8 rows x 128 B) of every K tile and of every V^T tile ------------
+    const T* Kg = reinterpret_cast<const T*>(a.k) + (int64_t)kvf * a.k_fs + h * D;
+    const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)kvf * a.vt_fs + (int64_t)(h * D) * a.ldvt;
+    const Rsrc rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Kg), 0, 0x7fffffff, 0x00020000);
+    const Rsrc rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Vg), 0, 0x7fffffff, 0x00020000);
+    const int prow = 8 * wave + (lane >> 3);                    // tile row this lane fetches
+    const int pch = (lane & 7) ^ ((prow >> 1) & 7);             // logical 16-B chunk stored at slot lane & 7 (XOR swizzle)
+    const int kvo = prow * (a.ldk * 2) + pch * 16;              // + key0 * ldk * 2 (scalar)
+    const int vvo = prow * (a.ldvt * 2) + pch * 16;             // + key0 * 2       (scalar)
+    auto dma_tile = [&](int t) __attribute__((always_inline)) {
+        char* st = smem + (t & (PNS - 1)) * PSTAGE + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)st, 16, kvo, t * PKT * a.ldk * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(st + 8192), 16, vvo, t * PKT * 2, 0, 0);
+    };
+
+    // ---- fragment read offsets: K rows with key bits 2 <-> 3 swapped (so P comes out in B-operand order), V^T rows = channels
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int kx = hi ^ ((krow >> 1) & 7), vx = hi ^ ((l31 >> 1) & 7);      // swz(r + 32) == swz(r)
+    const int koff = krow * 128, voff = 8192 + l31 * 128;
+
+    // ---- online-softmax state -----------------------------------------------------------------------
+    float m = 0.f;
+    bool fresh = true;
+    f32x16 o[2], ol, sc[2];
+    T8 pf[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf[i] = zero8<T>();
+
+    const int nt = a.l / PKT;
+    const int lead = 2 + grp;
+
+    // S(t) = K(t) Q'^T - m   and, when PV, O^T += V^T(t - 1) P(t - 1)^T : one burst of MFMAs, fragments two steps ahead
+    auto mslot = [&](int t, auto qk_tag, auto pv_tag) __attribute__((always_inline)) {
+        constexpr bool QK = decltype(qk_tag)::value, PV = decltype(pv_tag)::value;
+        const char* sk = smem + (t & (PNS - 1)) * PSTAGE;                  // K(t)
+        const char* sv = smem + ((t - 1) & (PNS - 1)) * PSTAGE;            // V^T(t - 1)
+        if (QK) {
+            f32x16 cneg;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cneg[r] = -m;
+            T8 kf[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                kf[0][b] = *reinterpret_cast<const T8*>(sk + koff + b * 4096 + ((0 ^ kx) << 4));
+                kf[1][b] = *reinterpret_cast<const T8*>(sk + koff + b * 4096 + ((2 ^ kx) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) sc[b] = mfma32(kf[ks & 1][b], qf[ks], ks ? sc[b] : cneg);
+                if (ks + 2 < 4) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        kf[ks & 1][b] = *reinterpret_cast<const T8*>(sk + koff + b * 4096 + (((2 * (ks + 2)) ^ kx) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (PV) {
+            T8 vf[2][2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                vf[0][d] = *reinterpret_cast<const T8*>(sv + voff + d * 4096 + ((0 ^ vx) << 4));
+                vf[1][d] = *reinterpret_cast<const T8*>(sv + voff + d * 4096 + ((2 ^ vx) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d) o[d] = mfma32(vf[kk & 1][d], pf[kk], o[d]);
+                ol = mfma32(onesf, pf[kk], ol);
+                if (kk + 2 < 4) {
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+                        vf[kk & 1][d] = *reinterpret_cast<const T8*>(sv + voff + d * 4096 + (((2 * (kk + 2)) ^ vx) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every LDS read of the slot is complete before its barrier
+    };
+
+    // P(t) = 2^S(t) (row reference raised first when the head-room of the storage type is exceeded), this wave's DMA pieces of
+    // tile t + lead, and the counted wait
+    auto vslot = [&](int t) __attribute__((always_inline)) {
+        if (t + lead < nt) dma_tile(t + lead);
+        float xm = fmaxf(sc[0][0], sc[0][1]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) xm = fmaxf(fmaxf(xm, sc[i >> 3][(2 * i) & 15]), sc[i >> 3][(2 * i + 1) & 15]);
+        if (fresh || __any(xm > XTH)) {
+            // slow path (first tile of the row, or a score out-grew the head-room): move the reference to the row maximum,
+            // rescale O (its ones row = l included) and shift this tile's arguments; PV(t - 1) is complete, O is at rest
+            const float rowmax = max_halves(xm);
+            const float shift = fresh ? rowmax : fmaxf(rowmax, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-shift);
+            m += shift;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; ol[r] *= alpha; }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[b][r] -= shift;
+            fresh = false;
+        }
+        // lane (q, hi): sc[b][r] belongs to key 32 b + 16 (r >> 3) + 8 hi + (r & 7) of the tile = k-step 2 b + (r >> 3) of PV
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x8 pv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
+                pf[2 * b + u] = cvt8<T>(pv);
+            }
+        if (t + lead < nt) wait_vm<2>();                        // everything but the two pieces just requested has landed
+        else               wait_vm<0>();
+    };
+
+    // fence between a slot's last MFMAs and the VALU code of the next slot that reads their results (20 wait states; the hazard
+    // recogniser does not see across the barrier's asm / branches — aid_attn.hip has the history)
+    auto settle = [&]() __attribute__((always_inline)) {
+        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(ol));
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(ol));
+    };
+
+    // ---- prologue: this wave's pieces of the first `lead` tiles; tiles 0 (and 1 for the late group) published ------------
+    const std::true_type Y{};
+    const std::false_type N{};
+    dma_tile(0);
+    if (1 < nt) dma_tile(1);
+    if (grp == 1 && 2 < nt) dma_tile(2);
+    if (grp == 1 && 2 < nt) wait_vm<2>();                       // tiles 0, 1 landed (group 0 reads K(1) before this group's V(0))
+    else if (grp == 0 && 1 < nt) wait_vm<2>();                  // tile 0 landed
+    else wait_vm<0>();
+    slot_barrier();
+    if (grp == 1) slot_barrier();                               // the second group runs one barrier behind
+    mslot(0, Y, N);
+    settle();
+    slot_barrier();
+    for (int t = 0; t + 1 < nt; ++t) {
+        vslot(t);
+        slot_barrier();
+        mslot(t + 1, Y, Y);                                     // S(t + 1) and O += V^T(t) P(t)^T
+        settle();
+        slot_barrier();
+    }
+    vslot(nt - 1);
+    slot_barrier();
+    mslot(nt, N, Y);                                            // O += V^T(nt - 1) P(nt - 1)^T
+    settle();
+    slot_barrier();
+    if (grp == 0) slot_barrier();                               // both groups pass the same number of barriers
+
+    // ---- finish: O / l, lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3} ----------------------
+    const float lv = ol[0];
+    const float partner = other_half(lv);                       // the row sum sits at the lanes of half 0
+    const float inv = 1.f / (hi ? partner : lv);
+    const int q = q0 + l31;
+    if (q < a.s) {
+        const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f) * inv;
+        T* orow = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q * a.ldo + h * D;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dv = 32 * d + 8 * g + 4 * hi;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * osc;
+                if (a.accumulate) v += up4<T>(*reinterpret_cast<const T4*>(orow + dv));
+                *reinterpret_cast<T4*>(orow + dv) = cvt4<T>(v);
+            }
+    }
+}
+
+}  // namespace
+
+// May the ping-pong kernel run the single-segment frames of this call?  d = 64, whole 64-key tiles, at least two of them.
+bool attn_pp_supported(const AidAttnArgs& a) {
+    return a.d == 64 && a.l % PKT == 0 && a.l >= 2 * PKT && a.ldk % 8 == 0 && a.ldvt % 8 == 0;
+}
+
+hipError_t attn_pp_launch(const AidAttnArgs& a, const int* frames, int n_list, hipStream_t stream) {
+    if (n_list < 1 || n_list > 32) return hipErrorInvalidValue;
+    AttnPPParams p;
+    p.a = a;
+    p.nqb = (a.s + 255) / 256;
+    p.n_list = n_list;
+    p.c2 = a.softmax_scale * 1.4426950408889634f;
+    for (int i = 0; i < 32; ++i) p.frames[i] = frames[i < n_list ? i : 0];
+    const size_t smem = (size_t)PNS * PSTAGE;
+    static PerDevice<bool> attr_set[2];
+    const int ti = a.dtype == AID_DTYPE_F16 ? 0 : 1;
+    bool* done = attr_set[ti].slot();
+    if (!done) return hipErrorInvalidDevice;
+    const void* fn = ti == 0 ? reinterpret_cast<const void*>(&aid_attn_pp_kernel<f16>)
+                             : reinterpret_cast<const void*>(&aid_attn_pp_kernel<bf16>);
+    if (!*done) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        *done = true;
+    }
+    const int grid = p.nqb * n_list * a.heads;
+    if (ti == 0) hipLaunchKernelGGL(aid_attn_pp_kernel<f16>, dim3(grid), dim3(512), smem, stream, p);
+    else         hipLaunchKernelGGL(aid_attn_pp_kernel<bf16>, dim3(grid), dim3(512), smem, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace aid
