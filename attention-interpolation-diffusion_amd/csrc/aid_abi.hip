@@ -355,11 +355,29 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     const double flops = per_seg * ((double)segs * (a.n_frames - a.n_plain) + a.n_plain);
     const double flops_exec = a.seg_executed > 0 ? per_seg * a.seg_executed : flops;
     const double bytes = 2.0 * (2.0 * a.n_frames * a.s * c + 2.0 * a.n_kv * a.l * c);
-    hipError_t e;
-    {
+    hipError_t e = hipSuccess;
+    // d = 64, whole key tiles: the frames with ONE key segment (a PLAIN call: all of them; an INNER / OUTER call: the PLAIN
+    // riders and the fused end-point frames) run on the ping-pong kernel, the others on aid_attn_kernel next to it.  Both
+    // kernels decide per frame ON THE DEVICE from the coefficients; the host-side counts below (n_plain, two end points) only
+    // decide whether the ping-pong launch is worth issuing and how the work is attributed in the profile.
+    const int n_single = a.mode == AID_MODE_PLAIN ? a.n_frames : a.n_plain + ((a.fused && a.n_frames - a.n_plain >= 2) ? 2 : 0);
+    // Measured (profiles/r03_attn_notes.txt): +3 % at S = 4096, -12 % at S = 1024 against the program-order kernel — the VALU slot
+    // is as long as the MFMA slot at d = 64, so the alternation buys little.  Built and tested, OFF unless ATTN_V2 = 1.
+    const bool use_pp = aid::tune(aid::TUNE_ATTN_V2) == 1 && aid::attn_pp_supported(a) && n_single > 0;
+    if (use_pp) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "aid_attn_pp<%s,d64>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16");
+        const double f1 = per_seg * n_single;
+        ProfScope ps(static_cast<hipStream_t>(stream), nm, f1, bytes * n_single / a.n_frames, f1);
+        e = aid::attn_pp_launch(a, static_cast<hipStream_t>(stream));
+        g_variant = "aid_attn_pp<d64>";
+    }
+    if (e == hipSuccess && !(use_pp && a.mode == AID_MODE_PLAIN)) {
         const char* nm = aid::attn_variant_name(a);
-        ProfScope ps(static_cast<hipStream_t>(stream), nm, flops, bytes, flops_exec);
-        e = aid::attn_launch(a, static_cast<hipStream_t>(stream), &g_variant);
+        const double fa = use_pp ? flops - per_seg * n_single : flops;
+        const double fx = use_pp ? flops_exec - per_seg * n_single : flops_exec;
+        ProfScope ps(static_cast<hipStream_t>(stream), nm, fa, use_pp ? bytes * (a.n_frames - n_single) / a.n_frames : bytes, fx);
+        e = aid::attn_launch(a, static_cast<hipStream_t>(stream), &g_variant, use_pp);
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
 }

@@ -63,6 +63,7 @@ struct AttnKParams {
     int32_t nqb;                        // q blocks per (frame, head)
     float   c2;                         // softmax_scale * log2(e)
     int32_t q_iters;                    // resident variant: q blocks a workgroup works through one after the other
+    int32_t skip_single;                // 1: frames with ONE key segment are run by aid_attn_pp_kernel (launched next to this one)
 };
 
 // Resident variant (short key sets: the 77 text tokens of cross-attention, IP-Adapter image tokens): every key segment of the
@@ -187,6 +188,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const int fr = (lid / p.nqb) % a.n_frames;
     const int h = lid / (p.nqb * a.n_frames);
     int q0 = (qb * (RES ? p.q_iters : 1) * NW + wave) * 32 * QB;
+    if (MODE != AID_MODE_PLAIN && p.skip_single) {      // the ping-pong kernel has this frame (same predicate there); before any barrier
+        const int kv_ = a.kv_map ? a.kv_map[fr] : fr;
+        const float c_ = a.coef[fr];
+        if (c_ < 0.f || (a.fused && ((c_ == 0.f && kv_ == a.begin) || (c_ == 1.f && kv_ == a.end)))) return;
+    }
 
     // zero both LDS buffers once where the head dim is padded (d = 40 / 80): pad columns of K / pad rows of V^T are
     // never staged and must be finite.  d = 64 / 160 have no padding that a fragment read touches.
@@ -1247,11 +1253,12 @@ const char* attn_variant_name(const AidAttnArgs& a) {
     return name;
 }
 
-hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** variant) {
+hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** variant, bool skip_single) {
     AttnKParams p;
     p.a = a;
     p.nqb = 0;
     p.q_iters = 1;
+    p.skip_single = skip_single ? 1 : 0;
     if (tune(TUNE_ATTN_ORDER) == 0) p.a.n_plain = 0;         // development knob: plain XCD order for mixed launches
     p.c2 = a.softmax_scale * 1.4426950408889634f;
     hipError_t e = (a.dtype == AID_DTYPE_F16) ? launch_d<f16>(p, stream) : launch_d<bf16>(p, stream);

@@ -5,8 +5,7 @@
 //
 //   One workgroup = 8 waves x 32 query rows of one (frame, head); waves w and w + 4 share a SIMD.  Waves 0-3 and waves 4-7
 //   run the same program ONE BARRIER APART, and the program alternates two slots per 64-key tile:
-//     M(t)   every MFMA of the tile in one burst: S(t) = K(t) Q'^T - m (8) and O^T += V^T(t-1) P(t-1)^T (12), operand
-//            fragments read from LDS two steps ahead — nothing else
+//     M(t)   every MFMA of the tile in one burst: S(t) = K(t) Q'^T - m (8) and O^T += V^T(t-1) P(t-1)^T (12) — nothing else
 //     V(t)   the VALU half: head-room check, P(t) = 2^S(t), rounding to the storage type; plus this wave's two LDS-DMA
 //            pieces of a tile further down the stream and the counted wait that publishes an earlier one
 //   so while one wave of a SIMD keeps the matrix pipe busy its partner does the exponentials, and vice versa.  In the
@@ -15,11 +14,8 @@
 //   K / V^T tiles go HBM -> LDS by DMA (no staging registers, no ds_write pass) into a ring of four 16 KB stages; rows are
 //   unpadded 128 B, bank conflicts are avoided by the XOR swizzle of the GEMM (on the DMA source address and on the read).
 //
-// Schedule (interval = the time between two workgroup barriers; group g = wave / 4 executes slot s of its program in interval
-// s + g):  M(t) in interval 2t + g, V(t) in 2t + 1 + g.  Tile t sits in ring stage t & 3 and is read in M(t) (K) and M(t+1) (V^T)
-// of both groups, i.e. through interval 2t + 3; a wave requests its pieces of tile j + 2 + g in V(j) (interval >= 2(j+2+g-4) + 4,
-// the first interval in which stage (j+2+g) & 3 is free) and retires with vmcnt(2), which leaves only the two just issued in
-// flight — every piece of tile T is then landed AND barrier-published before interval 2T, when group 0 reads K(T).
+// The M slot reads nothing: its sixteen operand fragments are requested in the V slot before it (like the GEMM's read slot) and
+// waited for behind the barrier.  The DMA / publication schedule is written out next to the main loop.
 #include <type_traits>
 
 #include "aid_common.hpp"
@@ -36,9 +32,8 @@ constexpr int PNS = 4;                  // ring depth
 struct AttnPPParams {
     AidAttnArgs a;
     int32_t nqb;                        // 256-row q blocks per (frame, head)
-    int32_t n_list;                     // frames this launch runs
     float   c2;                         // softmax_scale * log2(e)
-    int32_t frames[32];                 // their indices in the caller's batch
+    int32_t abl;                        // development builds (-DAID_ABLATIONS): timing ablations, results are garbage
 };
 
 typedef __amdgpu_buffer_rsrc_t Rsrc;
@@ -69,10 +64,18 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 
     const int lid = xcd_remap(blockIdx.x, gridDim.x);           // [head][frame][q block]: a (frame, head)'s blocks share an L2
     const int qb = lid % p.nqb;
-    const int fr = p.frames[(lid / p.nqb) % p.n_list];
-    const int h = lid / (p.nqb * p.n_list);
+    const int fr = (lid / p.nqb) % a.n_frames;
+    const int h = lid / (p.nqb * a.n_frames);
     const int q0 = (qb * 8 + wave) * 32;
     const int kvf = a.kv_map ? a.kv_map[fr] : fr;
+    // Frames with more than one key segment (interior frames of an INNER / OUTER call) belong to aid_attn_kernel, which is
+    // launched next to this kernel and skips the frames this one runs: BOTH evaluate the same predicate on the device
+    // coefficients, so the split is exact whatever the host-side hints say.
+    if (a.mode != AID_MODE_PLAIN) {
+        const float cf = a.coef[fr];
+        const bool single = cf < 0.f || (a.fused && ((cf == 0.f && kvf == a.begin) || (cf == 1.f && kvf == a.end)));
+        if (!single) return;
+    }
 
     // ---- Q fragments (B operand of the swapped product) -----------------------------------------
     T8 qf[4];
@@ -125,64 +128,76 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     for (int i = 0; i < 4; ++i) pf[i] = zero8<T>();
 
     const int nt = a.l / PKT;
-    const int lead = 2 + grp;
+    constexpr int LEAD = 3;             // a wave requests its pieces of tile j + 3 in V(j) and retires them in V(j + 1)
 
-    // S(t) = K(t) Q'^T - m   and, when PV, O^T += V^T(t - 1) P(t - 1)^T : one burst of MFMAs, fragments two steps ahead
-    auto mslot = [&](int t, auto qk_tag, auto pv_tag) __attribute__((always_inline)) {
+    // operand fragments of one M slot: K(t) for S(t) and V^T(t - 1) for the P V product, all four k-steps
+    T8 kf[4][2], vf[4][2];
+    auto read_k = [&](int t) __attribute__((always_inline)) {
+        const char* sk = smem + (t & (PNS - 1)) * PSTAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) kf[ks][b] = *reinterpret_cast<const T8*>(sk + koff + b * 4096 + (((2 * ks) ^ kx) << 4));
+    };
+    auto read_v = [&](int t) __attribute__((always_inline)) {
+        const char* sv = smem + (t & (PNS - 1)) * PSTAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) vf[kk][d] = *reinterpret_cast<const T8*>(sv + voff + d * 4096 + (((2 * kk) ^ vx) << 4));
+    };
+
+    // M slot: S(t) = K(t) Q'^T - m and O^T += V^T(t - 1) P(t - 1)^T from fragments that were read in the slot before — MFMAs only
+    auto mslot = [&](auto qk_tag, auto pv_tag) __attribute__((always_inline)) {
         constexpr bool QK = decltype(qk_tag)::value, PV = decltype(pv_tag)::value;
-        const char* sk = smem + (t & (PNS - 1)) * PSTAGE;                  // K(t)
-        const char* sv = smem + ((t - 1) & (PNS - 1)) * PSTAGE;            // V^T(t - 1)
+#ifdef AID_ABLATIONS
+        if (p.abl & 4) {                                        // 4: no MFMA slot at all
+            asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+            return;
+        }
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragment reads of the V slot (issued before the barrier)
+        __builtin_amdgcn_sched_barrier(0);
         if (QK) {
             f32x16 cneg;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cneg[r] = -m;
-            T8 kf[2][2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                kf[0][b] = *reinterpret_cast<const T8*>(sk + koff + b * 4096 + ((0 ^ kx) << 4));
-                kf[1][b] = *reinterpret_cast<const T8*>(sk + koff + b * 4096 + ((2 ^ kx) << 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) sc[b] = mfma32(kf[ks & 1][b], qf[ks], ks ? sc[b] : cneg);
-                if (ks + 2 < 4) {
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        kf[ks & 1][b] = *reinterpret_cast<const T8*>(sk + koff + b * 4096 + (((2 * (ks + 2)) ^ kx) << 4));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int b = 0; b < 2; ++b) sc[b] = mfma32(kf[ks][b], qf[ks], ks ? sc[b] : cneg);
         }
         if (PV) {
-            T8 vf[2][2];
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                vf[0][d] = *reinterpret_cast<const T8*>(sv + voff + d * 4096 + ((0 ^ vx) << 4));
-                vf[1][d] = *reinterpret_cast<const T8*>(sv + voff + d * 4096 + ((2 ^ vx) << 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                for (int d = 0; d < 2; ++d) o[d] = mfma32(vf[kk & 1][d], pf[kk], o[d]);
+                for (int d = 0; d < 2; ++d) o[d] = mfma32(vf[kk][d], pf[kk], o[d]);
                 ol = mfma32(onesf, pf[kk], ol);
-                if (kk + 2 < 4) {
-#pragma unroll
-                    for (int d = 0; d < 2; ++d)
-                        vf[kk & 1][d] = *reinterpret_cast<const T8*>(sv + voff + d * 4096 + (((2 * (kk + 2)) ^ vx) << 4));
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every LDS read of the slot is complete before its barrier
     };
 
-    // P(t) = 2^S(t) (row reference raised first when the head-room of the storage type is exceeded), this wave's DMA pieces of
-    // tile t + lead, and the counted wait
+    // V slot: P(t) = 2^S(t) (row reference raised first when the head-room of the storage type is exceeded); this wave's DMA
+    // pieces of tile t + LEAD; the fragment reads of the next M slot (K(t + 1), V^T(t)); the counted wait
     auto vslot = [&](int t) __attribute__((always_inline)) {
-        if (t + lead < nt) dma_tile(t + lead);
+        const bool issue = t + LEAD < nt;
+#ifdef AID_ABLATIONS
+        if (p.abl & 1) {                                        // 1: no VALU work in the V slot
+            if (!(p.abl & 2) && issue) dma_tile(t + LEAD);
+            fresh = false;
+            if (t + 1 < nt) read_k(t + 1);
+            read_v(t);
+            if (issue) wait_vm<2>(); else wait_vm<0>();
+            return;
+        }
+#endif
+        if (issue
+#ifdef AID_ABLATIONS
+            && !(p.abl & 2)
+#endif
+        ) dma_tile(t + LEAD);
+        if (t + 1 < nt) read_k(t + 1);                          // (published one V slot ago; they land while the VALU work runs)
+        read_v(t);
         float xm = fmaxf(sc[0][0], sc[0][1]);
 #pragma unroll
         for (int i = 1; i < 16; ++i) xm = fmaxf(fmaxf(xm, sc[i >> 3][(2 * i) & 15]), sc[i >> 3][(2 * i + 1) & 15]);
@@ -211,8 +226,8 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
                 pf[2 * b + u] = cvt8<T>(pv);
             }
-        if (t + lead < nt) wait_vm<2>();                        // everything but the two pieces just requested has landed
-        else               wait_vm<0>();
+        if (issue) wait_vm<2>();                                // everything but the two pieces just requested has landed
+        else       wait_vm<0>();
     };
 
     // fence between a slot's last MFMAs and the VALU code of the next slot that reads their results (20 wait states; the hazard
@@ -225,30 +240,33 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(ol));
     };
 
-    // ---- prologue: this wave's pieces of the first `lead` tiles; tiles 0 (and 1 for the late group) published ------------
+    // Schedule: group g executes M(t) in interval 2 t + g and V(t) in 2 t + 1 + g.  Tile T is read in V(T - 1) (K) and V(T) (V^T)
+    // of both groups = intervals 2 T - 1 .. 2 T + 2, every read complete (lgkmcnt) before the reader's next barrier, so stage
+    // T & 3 is free from interval 2 T + 3.  Tile U = T + 4 lands there: requested in V(U - 3) (interval 2 U - 5 + g >= 2 T + 3),
+    // retired by the vmcnt(2) of V(U - 2) (interval 2 U - 3 + g), barrier-published before interval 2 U - 1.
+    // ---- prologue: this wave's pieces of tiles 0 .. 2; tiles 0 and 1 published; fragments of K(0) ------------
     const std::true_type Y{};
     const std::false_type N{};
     dma_tile(0);
     if (1 < nt) dma_tile(1);
-    if (grp == 1 && 2 < nt) dma_tile(2);
-    if (grp == 1 && 2 < nt) wait_vm<2>();                       // tiles 0, 1 landed (group 0 reads K(1) before this group's V(0))
-    else if (grp == 0 && 1 < nt) wait_vm<2>();                  // tile 0 landed
-    else wait_vm<0>();
+    if (2 < nt) { dma_tile(2); wait_vm<2>(); }
+    else        wait_vm<0>();
     slot_barrier();
     if (grp == 1) slot_barrier();                               // the second group runs one barrier behind
-    mslot(0, Y, N);
+    read_k(0);
+    mslot(Y, N);
     settle();
     slot_barrier();
     for (int t = 0; t + 1 < nt; ++t) {
         vslot(t);
         slot_barrier();
-        mslot(t + 1, Y, Y);                                     // S(t + 1) and O += V^T(t) P(t)^T
+        mslot(Y, Y);                                            // S(t + 1) and O += V^T(t) P(t)^T
         settle();
         slot_barrier();
     }
     vslot(nt - 1);
     slot_barrier();
-    mslot(nt, N, Y);                                            // O += V^T(nt - 1) P(nt - 1)^T
+    mslot(N, Y);                                                // O += V^T(nt - 1) P(nt - 1)^T
     settle();
     slot_barrier();
     if (grp == 0) slot_barrier();                               // both groups pass the same number of barriers
@@ -282,14 +300,12 @@ bool attn_pp_supported(const AidAttnArgs& a) {
     return a.d == 64 && a.l % PKT == 0 && a.l >= 2 * PKT && a.ldk % 8 == 0 && a.ldvt % 8 == 0;
 }
 
-hipError_t attn_pp_launch(const AidAttnArgs& a, const int* frames, int n_list, hipStream_t stream) {
-    if (n_list < 1 || n_list > 32) return hipErrorInvalidValue;
+hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream) {
     AttnPPParams p;
     p.a = a;
     p.nqb = (a.s + 255) / 256;
-    p.n_list = n_list;
     p.c2 = a.softmax_scale * 1.4426950408889634f;
-    for (int i = 0; i < 32; ++i) p.frames[i] = frames[i < n_list ? i : 0];
+    p.abl = tune(TUNE_ATTN_RES_CHUNKS) > 100 ? tune(TUNE_ATTN_RES_CHUNKS) - 100 : 0;      // development builds only
     const size_t smem = (size_t)PNS * PSTAGE;
     static PerDevice<bool> attr_set[2];
     const int ti = a.dtype == AID_DTYPE_F16 ? 0 : 1;
@@ -302,7 +318,7 @@ hipError_t attn_pp_launch(const AidAttnArgs& a, const int* frames, int n_list, h
         if (e != hipSuccess) return e;
         *done = true;
     }
-    const int grid = p.nqb * n_list * a.heads;
+    const int grid = p.nqb * a.n_frames * a.heads;
     if (ti == 0) hipLaunchKernelGGL(aid_attn_pp_kernel<f16>, dim3(grid), dim3(512), smem, stream, p);
     else         hipLaunchKernelGGL(aid_attn_pp_kernel<bf16>, dim3(grid), dim3(512), smem, stream, p);
     return hipGetLastError();

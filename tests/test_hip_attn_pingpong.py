@@ -1,0 +1,131 @@
+"""GPU: the ping-pong attention kernel (csrc/aid_attn_pp.hip: d = 64, one key segment per frame, whole 64-key tiles; a built
+variant, enabled by the tuning knob ATTN_V2 = 1 — it measured +3 % / -12 % against the default kernel, profiles/r03_attn_notes.txt)
+against the fp64 oracle and against the program-order kernel.  A PLAIN call runs on it alone;
+in an INNER / OUTER call it takes the PLAIN riders and the fused end-point frames while aid_attn_kernel runs the interior
+frames next to it — both kernels split the frames by the same predicate on the DEVICE coefficients."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import aid_oracle as O
+from util import TOL, WORST, rel_l2, to_np64, worst
+
+pytestmark = pytest.mark.gpu
+
+import aid_amd  # noqa: E402
+from aid_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+DTYPES = [torch.float16, torch.bfloat16]
+ids_dt = lambda d: str(d).split(".")[-1]  # noqa: E731
+
+
+def _inputs(n, s, l, h, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    c = h * 64
+    q = torch.randn(n, s, c, generator=g).to(dtype)
+    k = torch.randn(n, l, c, generator=g).to(dtype)
+    v = torch.randn(n, l, c, generator=g).to(dtype)
+    return q, k, v, v.transpose(1, 2).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("shape", [(3, 256, 128, 2), (2, 300, 256, 1), (3, 1, 192, 2), (2, 1024, 1024, 3), (5, 97, 640, 1)],
+                         ids=lambda s: "n%d_s%d_l%d_h%d" % s)
+def test_plain_call_on_the_pingpong_kernel(dtype, shape, tuning):
+    tuning("ATTN_V2", 1)
+    n, s, l, h = shape
+    q, k, v, vt = _inputs(n, s, l, h, dtype, seed=s + l)
+    o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="plain")
+    assert "aid_attn_pp" in ops.last_attn_variant()
+    ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, 64 ** -0.5, "plain", False, None)
+    assert torch.isfinite(o).all()
+    assert rel_l2(to_np64(o), ref) < TOL[dtype] and worst(to_np64(o), ref) < WORST[dtype]
+    tuning("ATTN_V2", 0)
+    o_old = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="plain")
+    assert "aid_attn_pp" not in ops.last_attn_variant()
+    assert rel_l2(to_np64(o), to_np64(o_old)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("mode,fused", [("outer", True), ("outer", False), ("inner", True), ("inner", False)])
+def test_mixed_call_splits_the_frames_between_the_two_kernels(dtype, mode, fused, tuning):
+    """7 AID frames + 7 PLAIN riders (batched CFG): riders (and, when fused, the two end-point frames) on the ping-pong kernel,
+    interior frames on aid_attn_kernel; every frame against the oracle."""
+    tuning("ATTN_V2", 1)
+    n, s, l, h = 7, 200, 256, 2
+    q, k, v, vt = _inputs(2 * n, s, l, h, dtype, seed=77)
+    coef = torch.from_numpy(O.beta_coefs(n, 3, 3)).float()
+    cd = torch.cat([coef.to(dtype).float(), -torch.ones(n)])
+    o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused, coef=cd.to(DEV), begin=0, end=n - 1, n_plain=n)
+    q64, k64, v64 = to_np64(q), to_np64(k), to_np64(v)
+    ref = np.concatenate([O.attn_core(q64[:n], k64[:n], v64[:n], h, 64 ** -0.5, mode, fused, coef.to(dtype).float().numpy()),
+                          O.attn_core(q64[n:], k64[n:], v64[n:], h, 64 ** -0.5, "plain", False, None)])
+    for f in range(2 * n):
+        assert rel_l2(to_np64(o[f]), ref[f]) < TOL[dtype], (f, ops.last_attn_variant())
+    assert worst(to_np64(o), ref) < WORST[dtype]
+    # a WRONG rider hint must not change the result (the kernels decide on the device coefficients); only the launch choice moves
+    o2 = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused, coef=cd.to(DEV), begin=0, end=n - 1, n_plain=0)
+    assert rel_l2(to_np64(o2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+def test_forced_rescale_on_the_pingpong_kernel(dtype, tuning):
+    """Spiked keys late in the sequence push the row reference up after many tiles (the rare branch: O, its row-sum row and the
+    tile's arguments are rescaled in the VALU slot, between PV(t - 1) and PV(t))."""
+    tuning("ATTN_V2", 1)
+    n, s, l, h = 2, 64, 512, 1
+    q, k, v, vt = _inputs(n, s, l, h, dtype, seed=5)
+    k[:, 130] = q[:, 3] * 4.0
+    k[:, 300] = q[:, 9] * 5.0
+    k[:, 511] = q[:, 7] * 6.0
+    o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="plain")
+    assert "aid_attn_pp" in ops.last_attn_variant()
+    ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, 64 ** -0.5, "plain", False, None)
+    assert np.isfinite(to_np64(o)).all() and rel_l2(to_np64(o), ref) < TOL[dtype] and worst(to_np64(o), ref) < WORST[dtype]
+
+
+def test_accumulate_scales_kv_map_and_determinism(tuning):
+    tuning("ATTN_V2", 1)
+    dtype, n, s, l, h = torch.bfloat16, 4, 160, 128, 2
+    q, k, v, vt = _inputs(n, s, l, h, dtype, seed=9)
+    kv_map = torch.tensor([1, 1, 0, 2], dtype=torch.int32)
+    fs = torch.tensor([0.5, 1.0, 2.0, 0.25])
+    base = torch.randn(n, s, h * 64).to(dtype)
+    out = base.clone().to(DEV)
+    ops.attn_fwd(q.to(DEV), k[:3].contiguous().to(DEV), vt[:3].contiguous().to(DEV), h, l=l, mode="plain", kv_map=kv_map.to(DEV),
+                 frame_scale=fs.to(DEV), out_scale=0.7, accumulate=True, out=out)
+    assert "aid_attn_pp" in ops.last_attn_variant()
+    idx = kv_map.long()
+    ref = O.attn_core(to_np64(q), to_np64(k[idx]), to_np64(v[idx]), h, 64 ** -0.5, "plain", False, None)
+    ref = to_np64(base) + 0.7 * fs.numpy()[:, None, None] * ref
+    assert rel_l2(to_np64(out), ref) < TOL[dtype]
+    outs = []
+    for _ in range(3):
+        o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="plain")
+        outs.append(o.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+def test_full_size_sdxl_levels_sampled_rows(tuning):
+    """The two self-attention shapes of the SDXL stack (14 frames) on sampled frames / heads / rows."""
+    tuning("ATTN_V2", 1)
+    dtype = torch.bfloat16
+    for (s, h) in ((1024, 20), (4096, 10)):
+        n = 14 if s == 1024 else 4
+        g = torch.Generator().manual_seed(s)
+        c = h * 64
+        q = torch.randn(n, s, c, generator=g).to(dtype).to(DEV)
+        k = torch.randn(n, s, c, generator=g).to(dtype).to(DEV)
+        vt = torch.randn(n, c, s, generator=g).to(dtype).to(DEV)
+        o = ops.attn_fwd(q, k, vt, h, l=s, mode="plain")
+        assert "aid_attn_pp" in ops.last_attn_variant() and torch.isfinite(o).all()
+        rows = torch.tensor([0, 31, 32, 255, 256, 700, s - 1])
+        for f, hh in ((0, 0), (n - 1, h - 1), (n // 2, h // 2)):
+            sl = slice(hh * 64, hh * 64 + 64)
+            qs = to_np64(q[f, rows][:, sl]) * 64 ** -0.5
+            sc = qs @ to_np64(k[f, :, sl]).T
+            pr = np.exp(sc - sc.max(axis=1, keepdims=True))
+            pr /= pr.sum(axis=1, keepdims=True)
+            ref = pr @ to_np64(vt[f, sl, :]).T
+            assert rel_l2(to_np64(o[f, rows][:, sl]), ref) < TOL[dtype], (s, f, hh)

@@ -41,7 +41,10 @@ def one(fn):
     buf = (aid_amd._lib.AidProfileEntry * 4096)()
     n = lib.aid_profile_end(buf, 4096)
     e = [x for x in buf[:n] if x.kernel.decode().startswith("aid_attn")]
-    return sum(x.ms for x in e) / len(e) * 1e3, e[0].flops, e[0].flops_executed, e[0].kernel.decode()
+    calls = ITERS                                    # a call may be two launches (ping-pong kernel + program-order kernel)
+    per = len(e) // calls
+    return (sum(x.ms for x in e) / calls * 1e3, sum(x.flops for x in e[:per]), sum(x.flops_executed for x in e[:per]),
+            "+".join(x.kernel.decode().replace("aid_attn", "") for x in e[:per]))
 
 
 for grp in which:
@@ -62,17 +65,20 @@ for grp in which:
                                       begin=0, end=n - 1, out=out, n_plain=n if fused else 0, seg_executed=segx)
             res = {i: [] for i in range(len(variants))}
             names = {}
+            def apply(v):                                     # knobs are set through the library (aid_set_tuning), not the environment
+                for name in ("ATTN_NW", "ATTN_QB", "ATTN_PIPE", "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2"):
+                    ops.set_tuning(name, int(v.get(name, v.get("AID_" + name, -1))))
             for i, v in enumerate(variants):                  # warm every variant (lazy attributes)
-                os.environ.update(v); fn(); fn()
+                apply(v); fn(); fn()
             torch.cuda.synchronize()
             for r in range(ROUNDS):
                 for i, v in enumerate(variants):
-                    os.environ.update(v)
+                    apply(v)
                     us, fl, flx, nm = one(fn)
                     res[i].append(us); names[i] = (fl, flx, nm)
             for i, v in enumerate(variants):
                 us = statistics.median(res[i])
                 fl, flx, nm = names[i]
-                print(f"{tag:20s} {mode:6s} {str(v):28s} {nm:34s} {us:9.1f} us  alg {fl / us / 1e6:7.1f}  exec {flx / us / 1e6:7.1f} TF/s"
+                print(f"{tag:20s} {mode:6s} {str(v):22s} {nm:44s} {us:9.1f} us  alg {fl / us / 1e6:7.1f}  exec {flx / us / 1e6:7.1f} TF/s"
                       f"   (min {min(res[i]):.1f})", flush=True)
 print("done")
