@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const int kvo = prow * (a.ldk * 2) + pch * 16;              // + key0 * ldk * 2 (scalar)
     const int vvo = prow * (a.ldvt * 2) + pch * 16;             // + key0 * 2       (scalar)
     auto dma_tile = [&](int t) __attribute__((always_inline)) {
-        char* st = smem + (t & (PNS - 1)) * PSTAGE + wave * 1024;
+        char* st = smem + (t & (PNS - 1)) * PSTAGE + wave * 1024;        // t & 3 is a constant wherever the caller's is (main loop)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)st, 16, kvo, t * PKT * a.ldk * 2, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(st + 8192), 16, vvo, t * PKT * 2, 0, 0);
     };
@@ -116,11 +116,21 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
     const int kx = hi ^ ((krow >> 1) & 7), vx = hi ^ ((l31 >> 1) & 7);      // swz(r + 32) == swz(r)
     const int koff = krow * 128, voff = 8192 + l31 * 128;
+    int kad[4], vad[4];                 // per-lane LDS address of k-step ks inside a stage; stage and block go into the offset field
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kad[ks] = koff + (((2 * ks) ^ kx) << 4);
+        vad[ks] = voff + (((2 * ks) ^ vx) << 4);
+    }
 
     // ---- online-softmax state -----------------------------------------------------------------------
     float m = 0.f;
     bool fresh = true;
     f32x16 o[2], ol, sc[2];
+    f32x16 cneg;                        // -m as an accumulator block: the C operand of a tile's first score MFMAs, rebuilt on a rescale only
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cneg[r] = 0.f;
+    asm volatile("" : "+v"(cneg));
     T8 pf[4];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; }
@@ -133,18 +143,18 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // operand fragments of one M slot: K(t) for S(t) and V^T(t - 1) for the P V product, all four k-steps
     T8 kf[4][2], vf[4][2];
     auto read_k = [&](int t) __attribute__((always_inline)) {
-        const char* sk = smem + (t & (PNS - 1)) * PSTAGE;
+        const int so = (t & (PNS - 1)) * PSTAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) kf[ks][b] = *reinterpret_cast<const T8*>(sk + koff + b * 4096 + (((2 * ks) ^ kx) << 4));
+            for (int b = 0; b < 2; ++b) kf[ks][b] = *reinterpret_cast<const T8*>(smem + kad[ks] + (so + b * 4096));
     };
     auto read_v = [&](int t) __attribute__((always_inline)) {
-        const char* sv = smem + (t & (PNS - 1)) * PSTAGE;
+        const int so = (t & (PNS - 1)) * PSTAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int d = 0; d < 2; ++d) vf[kk][d] = *reinterpret_cast<const T8*>(sv + voff + d * 4096 + (((2 * kk) ^ vx) << 4));
+            for (int d = 0; d < 2; ++d) vf[kk][d] = *reinterpret_cast<const T8*>(smem + vad[kk] + (so + d * 4096));
     };
 
     // M slot: S(t) = K(t) Q'^T - m and O^T += V^T(t - 1) P(t - 1)^T from fragments that were read in the slot before — MFMAs only
@@ -159,9 +169,6 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragment reads of the V slot (issued before the barrier)
         __builtin_amdgcn_sched_barrier(0);
         if (QK) {
-            f32x16 cneg;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cneg[r] = -m;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -199,6 +206,9 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         if (t + 1 < nt) read_k(t + 1);                          // (published one V slot ago; they land while the VALU work runs)
         read_v(t);
         float xm = fmaxf(sc[0][0], sc[0][1]);
+#ifdef AID_ABLATIONS
+        if (!(p.abl & 8))                                       // 8: no head-room check (the maximum chain)
+#endif
 #pragma unroll
         for (int i = 1; i < 16; ++i) xm = fmaxf(fmaxf(xm, sc[i >> 3][(2 * i) & 15]), sc[i >> 3][(2 * i + 1) & 15]);
         if (fresh || __any(xm > XTH)) {
@@ -208,6 +218,9 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             const float shift = fresh ? rowmax : fmaxf(rowmax, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-shift);
             m += shift;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cneg[r] = -m;
+            asm volatile("" : "+v"(cneg));                      // (opaque: keeps hipcc from rebuilding the block in every M slot)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; ol[r] *= alpha; }
 #pragma unroll
@@ -257,12 +270,18 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     mslot(Y, N);
     settle();
     slot_barrier();
-    for (int t = 0; t + 1 < nt; ++t) {
-        vslot(t);
-        slot_barrier();
-        mslot(Y, Y);                                            // S(t + 1) and O += V^T(t) P(t)^T
-        settle();
-        slot_barrier();
+    // four tiles per trip: t & 3 — the ring stage of every DMA and fragment read — is a compile-time constant in each copy
+    for (int t4 = 0; t4 + 1 < nt; t4 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t4 + j;
+            if (t + 1 >= nt) break;
+            vslot(t);
+            slot_barrier();
+            mslot(Y, Y);                                        // S(t + 1) and O += V^T(t) P(t)^T
+            settle();
+            slot_barrier();
+        }
     }
     vslot(nt - 1);
     slot_barrier();

@@ -37,7 +37,7 @@ def _attn(tab):
 
 
 def test_no_kernel_spills_or_uses_scratch():
-    for obj in ("aid_attn", "aid_gemm", "aid_norm"):
+    for obj in ("aid_attn", "aid_attn_pp", "aid_gemm", "aid_norm"):
         for sym, r in _table(obj).items():
             assert r["scratch"] == 0 and r["spill"] == 0, (obj, sym, r)
 
@@ -48,7 +48,7 @@ def test_sgpr_spills_are_bounded():
     pointers, descriptors) out of the 102 SGPRs.  The GEMM and LayerNorm kernels spill none; the attention kernel's
     three-segment variants spill up to 30 (measured at this commit; they sit outside the tile loop: pointers of the
     segments not being walked).  VERDICT r2 weak #10."""
-    for obj, bound in (("aid_gemm", 0), ("aid_norm", 0), ("aid_attn", 32)):
+    for obj, bound in (("aid_gemm", 0), ("aid_norm", 0), ("aid_attn_pp", 8), ("aid_attn", 32)):
         for sym, r in _table(obj).items():
             assert r["sgpr_spill"] <= bound, (obj, sym, r)
 
