@@ -361,9 +361,13 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     // kernels decide per frame ON THE DEVICE from the coefficients; the host-side counts below (n_plain, two end points) only
     // decide whether the ping-pong launch is worth issuing and how the work is attributed in the profile.
     const int n_single = a.mode == AID_MODE_PLAIN ? a.n_frames : a.n_plain + ((a.fused && a.n_frames - a.n_plain >= 2) ? 2 : 0);
-    // Measured (profiles/r03_attn_notes.txt): +3 % at S = 4096, -12 % at S = 1024 against the program-order kernel — the VALU slot
-    // is as long as the MFMA slot at d = 64, so the alternation buys little.  Built and tested, OFF unless ATTN_V2 = 1.
-    const bool use_pp = aid::tune(aid::TUNE_ATTN_V2) == 1 && aid::attn_pp_supported(a) && n_single > 0;
+    // The ping-pong kernel (aid_attn_pp.hip) takes calls made of single-segment frames only, from 2048 keys up: +10 % at S = 4096;
+    // at S = 1024 its one workgroup per CU cannot hide the per-workgroup start-up (-12 %), and splitting a mixed INNER / OUTER
+    // call into two launches loses more than the riders gain (profiles/r03_attn_notes.txt).  Knob ATTN_V2: 0 never, 1 wherever
+    // it is supported (tests), default = this rule.
+    const int v2 = aid::tune(aid::TUNE_ATTN_V2);
+    const bool use_pp = n_single > 0 && aid::attn_pp_supported(a) &&
+                        (v2 == 1 || (v2 < 0 && n_single == a.n_frames && a.l >= 2048));
     if (use_pp) {
         char nm[64];
         snprintf(nm, sizeof(nm), "aid_attn_pp<%s,d64>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16");

@@ -5,17 +5,21 @@
 //
 //   One workgroup = 8 waves x 32 query rows of one (frame, head); waves w and w + 4 share a SIMD.  Waves 0-3 and waves 4-7
 //   run the same program ONE BARRIER APART, and the program alternates two slots per 64-key tile:
-//     M(t)   every MFMA of the tile in one burst: S(t) = K(t) Q'^T - m (8) and O^T += V^T(t-1) P(t-1)^T (12) — nothing else
+//     M(t)   every MFMA of the tile in one burst: S(t) = K(t) Q'^T - m (8), then O^T += V^T(t-1) P(t-1)^T (12); in their shadow,
+//            one per MFMA and in pinned program order, the 16 operand-fragment reads: V^T(t-1) beside the score MFMAs, K(t+1)
+//            beside the PV MFMAs into the registers the score MFMAs released.  No VALU instruction.
 //     V(t)   the VALU half: head-room check, P(t) = 2^S(t), rounding to the storage type; plus this wave's two LDS-DMA
-//            pieces of a tile further down the stream and the counted wait that publishes an earlier one
+//            pieces of tile t + 6 and the counted wait that retires its pieces of tile t + 3
 //   so while one wave of a SIMD keeps the matrix pipe busy its partner does the exponentials, and vice versa.  In the
 //   program-order kernel the three co-resident waves of a SIMD drift into the same phase and MFMA time and VALU time add up
 //   (1100 cycles per wave-tile for 640 of MFMA, profiles/r02_attn_notes.txt); here they are complementary by construction.
-//   K / V^T tiles go HBM -> LDS by DMA (no staging registers, no ds_write pass) into a ring of four 16 KB stages; rows are
+//   K / V^T tiles go HBM -> LDS by DMA (no staging registers, no ds_write pass) into a ring of eight 16 KB stages; rows are
 //   unpadded 128 B, bank conflicts are avoided by the XOR swizzle of the GEMM (on the DMA source address and on the read).
+//   The main loop is unrolled by eight so the ring stage is a constant: it sits in the offset field of every ds_read.
 //
-// The M slot reads nothing: its sixteen operand fragments are requested in the V slot before it (like the GEMM's read slot) and
-// waited for behind the barrier.  The DMA / publication schedule is written out next to the main loop.
+// Measured (profiles/r03_attn_notes.txt): S = 4096 plain 588 us against 648 for the program-order kernel; S = 1024 110 against 96
+// (one workgroup per CU: nothing hides the ~7 us start-up of a workgroup that lives 34 intervals).  aid_attn_fwd uses it for
+// single-segment calls from 2048 keys up.
 #include <type_traits>
 
 #include "aid_common.hpp"
@@ -27,7 +31,7 @@ namespace {
 
 constexpr int PKT = 64;                 // keys per tile
 constexpr int PSTAGE = 16384;           // bytes per ring stage: K tile [64 keys][128 B] + V^T tile [64 rows][128 B]
-constexpr int PNS = 4;                  // ring depth
+constexpr int PNS = 8;                  // ring depth (128 KB)
 
 struct AttnPPParams {
     AidAttnArgs a;
@@ -116,11 +120,14 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
     const int kx = hi ^ ((krow >> 1) & 7), vx = hi ^ ((l31 >> 1) & 7);      // swz(r + 32) == swz(r)
     const int koff = krow * 128, voff = 8192 + l31 * 128;
-    int kad[4], vad[4];                 // per-lane LDS address of k-step ks inside a stage; stage and block go into the offset field
+    // per-lane LDS address of k-step ks inside ring half 0 / 1; stage (within the half) and block go into the 16-bit offset field
+    int kad[2][4], vad[2][4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        kad[ks] = koff + (((2 * ks) ^ kx) << 4);
-        vad[ks] = voff + (((2 * ks) ^ vx) << 4);
+        kad[0][ks] = koff + (((2 * ks) ^ kx) << 4);
+        vad[0][ks] = voff + (((2 * ks) ^ vx) << 4);
+        kad[1][ks] = kad[0][ks] + 4 * PSTAGE;
+        vad[1][ks] = vad[0][ks] + 4 * PSTAGE;
     }
 
     // ---- online-softmax state -----------------------------------------------------------------------
@@ -128,73 +135,91 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     bool fresh = true;
     f32x16 o[2], ol, sc[2];
     f32x16 cneg;                        // -m as an accumulator block: the C operand of a tile's first score MFMAs, rebuilt on a rescale only
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cneg[r] = 0.f;
-    asm volatile("" : "+v"(cneg));
     T8 pf[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; cneg[r] = 0.f; }
+    asm volatile("" : "+v"(cneg));
 #pragma unroll
     for (int i = 0; i < 4; ++i) pf[i] = zero8<T>();
 
     const int nt = a.l / PKT;
-    constexpr int LEAD = 3;             // a wave requests its pieces of tile j + 3 in V(j) and retires them in V(j + 1)
+#ifdef AID_ABLATIONS
+    // 16: slot timing — shader cycles of [V work | wait at the barrier behind it | M work | wait at the barrier behind it], summed over the
+    // tiles and written over the output rows (lane 0 of every wave: four floats = cycles per tile)
+    long long tmark = 0;
+    float tacc[4] = {0.f, 0.f, 0.f, 0.f};
+    auto stamp = [&](int which) __attribute__((always_inline)) {
+        if (p.abl & 16) {
+            __builtin_amdgcn_sched_barrier(0);
+            const long long now = clock64();
+            tacc[which] += (float)(now - tmark);
+            tmark = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#define PP_STAMP(i) stamp(i)
+#else
+#define PP_STAMP(i)
+#endif
 
-    // operand fragments of one M slot: K(t) for S(t) and V^T(t - 1) for the P V product, all four k-steps
+    // operand fragments: kf = K(t + 1) for S(t + 1), vf = V^T(t) for O += V^T(t) P(t)^T, all four k-steps each
     T8 kf[4][2], vf[4][2];
-    auto read_k = [&](int t) __attribute__((always_inline)) {
-        const int so = (t & (PNS - 1)) * PSTAGE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) kf[ks][b] = *reinterpret_cast<const T8*>(smem + kad[ks] + (so + b * 4096));
+    auto lds_k = [&](int st, int ks, int b) __attribute__((always_inline)) {           // st: ring stage, a constant wherever it matters
+        return *reinterpret_cast<const T8*>(smem + kad[st >> 2][ks] + ((st & 3) * PSTAGE + b * 4096));
     };
-    auto read_v = [&](int t) __attribute__((always_inline)) {
-        const int so = (t & (PNS - 1)) * PSTAGE;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int d = 0; d < 2; ++d) vf[kk][d] = *reinterpret_cast<const T8*>(smem + vad[kk] + (so + d * 4096));
+    auto lds_v = [&](int st, int kk, int d) __attribute__((always_inline)) {
+        return *reinterpret_cast<const T8*>(smem + vad[st >> 2][kk] + ((st & 3) * PSTAGE + d * 4096));
     };
+    auto pin = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
-    // M slot: S(t) = K(t) Q'^T - m and O^T += V^T(t - 1) P(t - 1)^T from fragments that were read in the slot before — MFMAs only
-    auto mslot = [&](auto qk_tag, auto pv_tag) __attribute__((always_inline)) {
-        constexpr bool QK = decltype(qk_tag)::value, PV = decltype(pv_tag)::value;
+    // M slot of the main loop — S(t + 1) = K(t + 1) Q'^T - m, then O^T += V^T(t) P(t)^T — and the fragment reads that ride in its
+    // shadow, one per MFMA, program order pinned:  V^T(t) (stage sv) beside the eight score MFMAs, which use the K fragments read
+    // one M slot ago; K(t + 2) (stage sk) beside PV MFMAs 2 .. 9, into the registers the score MFMAs have released.  No VALU.
+    auto mslot = [&](int sv, int sk) __attribute__((always_inline)) {
 #ifdef AID_ABLATIONS
         if (p.abl & 4) {                                        // 4: no MFMA slot at all
             asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
             return;
         }
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragment reads of the V slot (issued before the barrier)
-        __builtin_amdgcn_sched_barrier(0);
-        if (QK) {
+        pin();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) sc[b] = mfma32(kf[ks][b], qf[ks], ks ? sc[b] : cneg);
+        for (int i = 0; i < 8; ++i) {
+            const int ks = i >> 1, b = i & 1;
+            vf[ks][b] = lds_v(sv, ks, b);
+            pin();
+            sc[b] = mfma32(kf[ks][b], qf[ks], ks ? sc[b] : cneg);
+            pin();
         }
-        if (PV) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                for (int d = 0; d < 2; ++d) o[d] = mfma32(vf[kk][d], pf[kk], o[d]);
-                ol = mfma32(onesf, pf[kk], ol);
+        for (int i = 0; i < 12; ++i) {
+            const int kk = i / 3, w = i % 3;
+            if (w < 2) o[w] = mfma32(vf[kk][w], pf[kk], o[w]);
+            else       ol = mfma32(onesf, pf[kk], ol);
+            pin();
+            if (i >= 2 && i < 10) {
+                kf[(i - 2) >> 1][(i - 2) & 1] = lds_k(sk, (i - 2) >> 1, (i - 2) & 1);
+                pin();
             }
         }
     };
 
-    // V slot: P(t) = 2^S(t) (row reference raised first when the head-room of the storage type is exceeded); this wave's DMA
-    // pieces of tile t + LEAD; the fragment reads of the next M slot (K(t + 1), V^T(t)); the counted wait
+    // V slot: P(t) = 2^S(t) (row reference raised first when the head-room of the storage type is exceeded), rounded to the storage
+    // type; this wave's two DMA pieces of tile t + LEAD; the counted wait that retires its pieces of tile t + 3
+    constexpr int LEAD = 6;
+    auto retire = [&](int r) __attribute__((always_inline)) {   // r = tiles that may stay in flight behind the one being retired
+        if (r >= 3)      wait_vm<6>();
+        else if (r == 2) wait_vm<4>();
+        else if (r == 1) wait_vm<2>();
+        else             wait_vm<0>();
+    };
     auto vslot = [&](int t) __attribute__((always_inline)) {
         const bool issue = t + LEAD < nt;
 #ifdef AID_ABLATIONS
         if (p.abl & 1) {                                        // 1: no VALU work in the V slot
             if (!(p.abl & 2) && issue) dma_tile(t + LEAD);
             fresh = false;
-            if (t + 1 < nt) read_k(t + 1);
-            read_v(t);
-            if (issue) wait_vm<2>(); else wait_vm<0>();
+            retire(nt - 4 - t);
             return;
         }
 #endif
@@ -203,8 +228,6 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             && !(p.abl & 2)
 #endif
         ) dma_tile(t + LEAD);
-        if (t + 1 < nt) read_k(t + 1);                          // (published one V slot ago; they land while the VALU work runs)
-        read_v(t);
         float xm = fmaxf(sc[0][0], sc[0][1]);
 #ifdef AID_ABLATIONS
         if (!(p.abl & 8))                                       // 8: no head-room check (the maximum chain)
@@ -239,8 +262,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
                 pf[2 * b + u] = cvt8<T>(pv);
             }
-        if (issue) wait_vm<2>();                                // everything but the two pieces just requested has landed
-        else       wait_vm<0>();
+        retire(nt - 4 - t);
     };
 
     // fence between a slot's last MFMAs and the VALU code of the next slot that reads their results (20 wait states; the hazard
@@ -253,44 +275,76 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(ol));
     };
 
-    // Schedule: group g executes M(t) in interval 2 t + g and V(t) in 2 t + 1 + g.  Tile T is read in V(T - 1) (K) and V(T) (V^T)
-    // of both groups = intervals 2 T - 1 .. 2 T + 2, every read complete (lgkmcnt) before the reader's next barrier, so stage
-    // T & 3 is free from interval 2 T + 3.  Tile U = T + 4 lands there: requested in V(U - 3) (interval 2 U - 5 + g >= 2 T + 3),
-    // retired by the vmcnt(2) of V(U - 2) (interval 2 U - 3 + g), barrier-published before interval 2 U - 1.
-    // ---- prologue: this wave's pieces of tiles 0 .. 2; tiles 0 and 1 published; fragments of K(0) ------------
-    const std::true_type Y{};
-    const std::false_type N{};
-    dma_tile(0);
-    if (1 < nt) dma_tile(1);
-    if (2 < nt) { dma_tile(2); wait_vm<2>(); }
-    else        wait_vm<0>();
+    // Schedule.  Group g runs M(t) in interval 2 t + g and V(t) in 2 t + 1 + g (M(t) computes S(t) and the PV product of tile t - 1).
+    // Tile T is read in M(T - 1) (K, for the next slot's scores) and in M(T + 1) (V^T) = intervals 2 T - 2 .. 2 T + 3; every read is
+    // complete (lgkmcnt) before its reader's next barrier, so stage T & 7 is free from interval 2 T + 4.  Tile U = T + 8 lands there:
+    // requested in V(U - 6) (interval 2 U - 11 + g >= 2 T + 5), retired by the counted wait of V(U - 3) — three tile periods later —
+    // and barrier-published at the end of interval 2 U - 4 at the latest, two intervals before M(U - 1) reads it.
+    // ---- prologue: pieces of tiles 0 .. 5 requested, 0 .. 2 retired and published; S(0); fragments of K(1) ----------------
+#pragma unroll
+    for (int t = 0; t < LEAD; ++t)
+        if (t < nt) dma_tile(t);
+    retire(nt - 3);
     slot_barrier();
     if (grp == 1) slot_barrier();                               // the second group runs one barrier behind
-    read_k(0);
-    mslot(Y, N);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kf[i >> 1][i & 1] = lds_k(0, i >> 1, i & 1);
+#ifdef AID_ABLATIONS
+    if (!(p.abl & 4))
+#endif
+    {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sc[i & 1] = mfma32(kf[i >> 1][i & 1], qf[i >> 1], (i >> 1) ? sc[i & 1] : cneg);
+        pin();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kf[i >> 1][i & 1] = lds_k(1, i >> 1, i & 1);      // nt >= 2
+    }
     settle();
     slot_barrier();
-    // four tiles per trip: t & 3 — the ring stage of every DMA and fragment read — is a compile-time constant in each copy
-    for (int t4 = 0; t4 + 1 < nt; t4 += 4) {
+    // eight tiles per trip: t & 7 — the ring stage of every DMA and fragment read — is a compile-time constant in each copy
+    for (int t8 = 0; t8 + 1 < nt; t8 += 8) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = t4 + j;
+        for (int j = 0; j < 8; ++j) {
+            const int t = t8 + j;
             if (t + 1 >= nt) break;
+            PP_STAMP(3);
             vslot(t);
+            PP_STAMP(0);
             slot_barrier();
-            mslot(Y, Y);                                        // S(t + 1) and O += V^T(t) P(t)^T
+            PP_STAMP(1);
+            mslot(j, (j + 2) & 7);                              // (the K(t + 2) reads past the last tile fetch stale ring bytes, unused)
             settle();
+            PP_STAMP(2);
             slot_barrier();
         }
     }
     vslot(nt - 1);
     slot_barrier();
-    mslot(N, Y);                                                // O += V^T(nt - 1) P(nt - 1)^T
+    {                                                           // O += V^T(nt - 1) P(nt - 1)^T
+        const int so = ((nt - 1) & 7) * PSTAGE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vf[i >> 1][i & 1] = *reinterpret_cast<const T8*>(smem + vad[0][i >> 1] + so + (i & 1) * 4096);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) o[d] = mfma32(vf[kk][d], pf[kk], o[d]);
+            ol = mfma32(onesf, pf[kk], ol);
+        }
+    }
     settle();
     slot_barrier();
     if (grp == 0) slot_barrier();                               // both groups pass the same number of barriers
 
     // ---- finish: O / l, lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3} ----------------------
+#ifdef AID_ABLATIONS
+    if (p.abl & 16) {
+        if (lane == 0 && q0 < a.s) {
+            float* dbg = reinterpret_cast<float*>(reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q0 * a.ldo + h * D);
+            for (int i = 0; i < 4; ++i) dbg[i] = tacc[i] / (float)(nt - 1);
+        }
+        return;
+    }
+#endif
     const float lv = ol[0];
     const float partner = other_half(lv);                       // the row sum sits at the lanes of half 0
     const float inv = 1.f / (hi ? partner : lv);
