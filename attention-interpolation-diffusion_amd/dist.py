@@ -16,6 +16,7 @@ coefficients from rank 0 and ``all_gather`` of the final latents of the owned fr
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
@@ -154,6 +155,8 @@ class EndpointExchange:
         self.local_begin = 0 if rank == self.owner_begin else None              # local row of frame 0 on its owner
         self.local_end = (b - a - 1) if rank == self.owner_end else None         # local row of frame N-1 on its owner
         self.calls = 0
+        self.overlap = True                 # device tensors: broadcasts on a side stream, one event per layer (exchange_async)
+        self._side = {}
 
     def _bcast(self, t: torch.Tensor, src: int) -> None:
         if not (dist.is_available() and dist.is_initialized()):
@@ -167,17 +170,57 @@ class EndpointExchange:
         else:
             dist.broadcast(t, src=src, group=self.group)
 
-    def exchange(self, k: torch.Tensor, vt: torch.Tensor, n: int) -> Tuple[int, int]:
+    def _side_stream(self, device: torch.device):
+        s = self._side.get(device)
+        if s is None:
+            s = self._side[device] = torch.cuda.Stream(device=device)
+        return s
+
+    def exchange_async(self, k: torch.Tensor, vt: torch.Tensor, n: int) -> "PendingExchange":
+        """Start the hand-off and return at once: on device tensors the copies and the four broadcasts are enqueued on a
+        SIDE stream behind the work already on the caller's stream (the k / v projection), with one event recorded behind
+        them; the caller keeps its own stream busy (the layer's q projection) and calls ``.wait()`` on the result right
+        before the attention launch, which makes its stream wait for that event — no host synchronisation anywhere.
+        On host tensors (gloo development mode) the exchange completes inside this call."""
         if k.shape[0] != n + 2 or vt.shape[0] != n + 2:
             raise ValueError("k / vt need two free rows behind the local frames (ops.project_kv(extra_rows=2))")
-        for row, local, src in ((n, self.local_begin, self.owner_begin), (n + 1, self.local_end, self.owner_end)):
-            if local is not None:
-                k[row].copy_(k[local])
-                vt[row].copy_(vt[local])
-            self._bcast(k[row], src)
-            self._bcast(vt[row], src)
+        side = event = None
+        if k.is_cuda and self.overlap:
+            cur = torch.cuda.current_stream(k.device)
+            side = self._side_stream(k.device)
+            side.wait_stream(cur)                                   # rows 0 .. n - 1 are written by work queued on `cur`
+            k.record_stream(side)
+            vt.record_stream(side)
+        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+        with ctx:
+            for row, local, src in ((n, self.local_begin, self.owner_begin), (n + 1, self.local_end, self.owner_end)):
+                if local is not None:
+                    k[row].copy_(k[local])
+                    vt[row].copy_(vt[local])
+                self._bcast(k[row], src)
+                self._bcast(vt[row], src)
+            if side is not None:
+                event = torch.cuda.Event()
+                event.record(side)
         self.calls += 1
-        return n, n + 1
+        return PendingExchange(n, n + 1, event)
+
+    def exchange(self, k: torch.Tensor, vt: torch.Tensor, n: int) -> Tuple[int, int]:
+        return self.exchange_async(k, vt, n).wait()
+
+
+class PendingExchange:
+    """Result of ``EndpointExchange.exchange_async``: ``wait()`` orders the caller's CURRENT stream behind the exchange
+    (a device-side event wait) and returns the (begin, end) rows for the attention call."""
+
+    def __init__(self, begin: int, end: int, event=None):
+        self.begin, self.end, self.event = begin, end, event
+
+    def wait(self) -> Tuple[int, int]:
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.event = None
+        return self.begin, self.end
 
 
 def decode_sharded(decode, latents_local: torch.Tensor, shard: FrameShard, group=None) -> torch.Tensor:

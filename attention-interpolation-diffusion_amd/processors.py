@@ -349,24 +349,32 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
     ctx_index = proc.ctx_index if ctx_index is None else ctx_index
     exchange = getattr(proc, "endpoint_exchange", None)
     if exchange is not None and mode != "plain":
-        if ln is not None or add_to is not None or ctx_index is not None:
-            raise NotImplementedError("the end-point exchange layout runs the plain processor call (no sublayer fusion, "
-                                      "no shared-context map)")
+        if ln is not None or add_to is not None:
+            raise NotImplementedError("the end-point exchange layout runs the plain processor call (no sublayer fusion)")
         n = x.shape[0]
         if ctx is None:                               # self-attention: keys / values of frames 0 / N-1 come from their owners
-            q = ops.linear(x, wq)
+            # the four broadcasts run on the exchange's side stream while this stream does the q projection; one event per layer
             k, vt = ops.project_kv(x, wk, wv, extra_rows=2)
-            begin, end = exchange.exchange(k, vt, n)
+            pending = exchange.exchange_async(k, vt, n)
+            q = ops.linear(x, wq)
+            begin, end = pending.wait()
             o = ops.attn_fwd(q, k, vt, attn.heads, l=x.shape[1], mode=mode, fused=proc.is_fused, coef=coef,
                              begin=begin, end=end, n_plain=proc.plain_tail)
             return _epilogue(attn, ops.linear(o, wo, bo), residual, shape4)
         if proc.endpoint_ctx is None:
             raise RuntimeError("endpoint_exchange is set: cross-attention needs `endpoint_ctx` (text contexts of the two "
                                "end-point frames)")
+        # local frames keep their (possibly shared) context rows; the two end-point contexts are appended behind them
+        base = [int(i) for i in ctx_index] if ctx_index is not None else list(range(n))
+        if ctx_index is not None and ctx.shape[0] == n and max(base) + 1 != n:
+            ctx = ctx.index_select(0, torch.tensor([base.index(r) for r in range(max(base) + 1)], device=ctx.device))
+        nctx = max(base) + 1
+        if ctx.shape[0] != nctx:
+            raise RuntimeError(f"encoder_hidden_states has {ctx.shape[0]} rows; the frame -> context map needs {nctx}")
         ctx = torch.cat([ctx, proc.endpoint_ctx.to(ctx.dtype)], dim=0).contiguous()
-        _, ctx_map, _ = _shared_context(proc._ctx_cache, list(range(n)) + [n, n + 1], ctx, n + 2)
+        ctx, ctx_map, _ = _shared_context(proc._ctx_cache, base + [nctx, nctx + 1], ctx, n + 2)
         y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode, fused=proc.is_fused, coef=coef,
-                              begin=n, end=n + 1, ctx_map=ctx_map[:n], n_plain=proc.plain_tail)
+                              begin=nctx, end=nctx + 1, ctx_map=ctx_map[:n], n_plain=proc.plain_tail)
         return _epilogue(attn, y, residual, shape4)
     if ctx is not None and ctx_index is not None:
         ctx, ctx_map, idx = _shared_context(proc._ctx_cache, ctx_index, ctx, x.shape[0])

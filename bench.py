@@ -85,6 +85,10 @@ def parse():
                     help="project the text keys / values in every cross-attention call like the reference does (default: "
                          "once per layer and context; the contexts do not change over the steps)")
     ap.add_argument("--dtype", default=None, choices=["f16", "bf16"], help="override the workload's storage dtype")
+    ap.add_argument("--endpoints", default="replicate", choices=["replicate", "exchange"],
+                    help="N > 1 layouts (SURVEY §8e / §8f.4): every rank recomputes the two end-point frames (no per-layer collective) | "
+                         "ranks run their owned frames only and the owners broadcast the end points' keys / values per self-attention "
+                         "layer on a side stream (eager launches, no fused sublayers)")
     return ap.parse_args()
 
 
@@ -288,7 +292,8 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
         n_total = args.frames_per_gpu * world
     else:
         n_total = frames_default
-    shard = adist.frame_shard(n_total, world, rank)
+    exch = args.endpoints == "exchange"
+    shard = adist.owned_shard(n_total, world, rank) if exch else adist.frame_shard(n_total, world, rank)
     guided = guide_default if args.guide_prompt == "auto" else args.guide_prompt == "on"
     if name == "ip":
         guided = False
@@ -313,6 +318,7 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
             named.update(ip_pos=ip_pos, ip_neg=ip_neg)
         adist.broadcast_conditioning(named, src=0)
     xs = {k: adist.shard_rows(v, shard) for k, v in xs.items()}
+    end_ctx = torch.stack([cond[global_ctx[0]], cond[global_ctx[-1]]]) if exch else None    # text contexts of frames 0 / N-1
     rows = [global_ctx[f] for f in shard.index]              # context row of every local frame ...
     used = sorted(set(rows), key=rows.index)                 # ... renumbered in order of first local use
     ctx_index = [used.index(r) for r in rows] if guided else None
@@ -330,6 +336,13 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
         batched = False                      # the two passes carry different image embeddings: two UNet calls, like the reference
     else:
         install_sequence_processors(unet, shard.n_local, early=early, num_inference_steps=steps, coef=local_coef)
+    if exch:
+        if name == "ip" or args.sublayers != "off":
+            raise SystemExit("--endpoints exchange: text processors, --sublayers off")
+        ex = adist.EndpointExchange(n_total, world, rank)
+        for p in unet.attn_processors.values():
+            p.endpoint_exchange, p.endpoint_ctx = ex, end_ctx
+        args.no_graph = True                 # a collective per layer: eager launches
     loop = AidDenoiseLoop(unet, xs, cond, uncond, num_inference_steps=steps, warmup_ratio=args.warmup_ratio,
                           use_graphs=not args.no_graph, batched_cfg=batched, ctx_index=ctx_index)
     return dict(name=name, stack=stack, dtype=dt, early=early, what=what, n_total=n_total, shard=shard, guided=guided,
@@ -447,16 +460,21 @@ def main():
                         "each step and re-projects them 50 times); `also.sdxl_text_kv_per_call` times the per-call projection"
                         if not args.no_text_kv_cache else "projected in every cross-attention call (like the reference)"),
             "coef": f"BetaPPF(alpha=beta={steps})", "hipgraph": not args.no_graph,
-            "parallelism": f"frame-shard x{world} (replicated end points, no per-layer collective)",
+            "parallelism": (f"frame-shard x{world} (replicated end points, no per-layer collective)" if args.endpoints == "replicate"
+                            else f"frame-shard x{world} (owned frames only; end-point keys / values broadcast per self-attention "
+                                 "layer on a side stream)"),
             "ranks": world, "backend": backend,
-            "expected_speedup_vs_1gpu": adist.expected_speedup(wl["n_total"], world),
+            "expected_speedup_vs_1gpu": (adist.expected_speedup(wl["n_total"], world) if args.endpoints == "replicate"
+                                         else wl["n_total"] / max(adist.owned_shard(wl["n_total"], world, r).n_local
+                                                                  for r in range(world))),
         },
     }
     if name == "ip":
         result["config"]["ip_adapter"] = (f"{args.ip_tokens} image tokens per frame, image embeddings [3 N, 1, T, Cc]; AID pass = "
                                           f"{wl['early']} IP processors, other passes = IP-Adapter attention (text + scale x image)")
     if world > 1:
-        mlb = max(adist.frame_shard(wl["n_total"], world, r).n_local for r in range(world))
+        mk = adist.owned_shard if args.endpoints == "exchange" else adist.frame_shard
+        mlb = max(mk(wl["n_total"], world, r).n_local for r in range(world))
         result["config"]["max_local_batch"] = mlb
         # what the busiest rank delivers, in frames of ITS batch per second: compare with the 1-GPU line at that batch size
         # (replicated end points make the ideal speed-up n_total / max_local_batch, not the rank count)

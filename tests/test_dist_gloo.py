@@ -113,8 +113,9 @@ def _worker_f4(rank, world, port, n_frames, q):
         ex = adist.EndpointExchange(n_frames, world, rank)
         k = torch.cat([kf[list(sh.index)], torch.full((2, 6, 8), float("nan"))])
         vt = torch.cat([vf[list(sh.index)], torch.full((2, 8, 8), float("nan"))])
-        b, e = ex.exchange(k, vt, n)
-        ok = (b, e) == (n, n + 1) and torch.equal(k[b], kf[0]) and torch.equal(k[e], kf[-1]) \
+        pend = ex.exchange_async(k, vt, n)                          # host tensors: complete on return, no event
+        b, e = pend.wait()
+        ok = pend.event is None and (b, e) == (n, n + 1) and torch.equal(k[b], kf[0]) and torch.equal(k[e], kf[-1]) \
             and torch.equal(vt[b], vf[0]) and torch.equal(vt[e], vf[-1]) and torch.equal(k[:n], kf[list(sh.index)])
         lat = torch.arange(n_frames, dtype=torch.float32).view(-1, 1, 1, 1).expand(n_frames, 4, 2, 2)[list(sh.index)]
         imgs = adist.decode_sharded(lambda z: z.repeat(1, 1, 2, 2)[:, :3] * 2.0, lat, sh)

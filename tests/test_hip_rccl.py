@@ -77,13 +77,22 @@ def test_endpoint_exchange_layout_equals_replicated_layout(kind, cross):
     y = own(attn, x, encoder_hidden_states=ctx)
     assert rel_l2(to_np64(y), ref) < TOL[dtype]
     assert own.endpoint_exchange.calls == (0 if cross else 1)
+    if not cross:
+        # the hand-off runs on the exchange's side stream behind the k / v projection, the q projection overlaps it, one event
+        # orders the attention launch behind it: same bits as the in-line (current-stream) exchange, call after call
+        own.endpoint_exchange.overlap = False
+        y0 = own(attn, x, encoder_hidden_states=None)
+        own.endpoint_exchange.overlap = True
+        for _ in range(5):
+            assert torch.equal(own(attn, x, encoder_hidden_states=None), y0)
+        assert len(own.endpoint_exchange._side) == 1
 
     # an interior "rank": only frames 1..N-2 in the batch; its exchange object is fed by a stand-in for the owners
     class FromOwners(adist.EndpointExchange):
-        def exchange(self, k, vt, m):
+        def exchange_async(self, k, vt, m):
             kk, vv = aid_amd.ops.project_kv(x[[0, n - 1]].contiguous(), attn.to_k.weight, attn.to_v.weight)
             k[m], k[m + 1], vt[m], vt[m + 1] = kk[0], kk[1], vv[0], vv[1]
-            return m, m + 1
+            return adist.PendingExchange(m, m + 1)
     inner = cls(size=n - 2, is_fused=True)
     inner.coef = full.coef[1:-1].clone()
     inner.endpoint_exchange = FromOwners(n, 1, 0)
