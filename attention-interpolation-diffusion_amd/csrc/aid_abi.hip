@@ -356,27 +356,29 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     const double flops_exec = a.seg_executed > 0 ? per_seg * a.seg_executed : flops;
     const double bytes = 2.0 * (2.0 * a.n_frames * a.s * c + 2.0 * a.n_kv * a.l * c);
     hipError_t e = hipSuccess;
-    // d = 64, whole key tiles: the frames with ONE key segment (a PLAIN call: all of them; an INNER / OUTER call: the PLAIN
-    // riders and the fused end-point frames) run on the ping-pong kernel, the others on aid_attn_kernel next to it.  Both
-    // kernels decide per frame ON THE DEVICE from the coefficients; the host-side counts below (n_plain, two end points) only
-    // decide whether the ping-pong launch is worth issuing and how the work is attributed in the profile.
+    // d = 64, whole key tiles: the ping-pong kernel (aid_attn_pp.hip).  It runs the frames with ONE key segment (a PLAIN call: all of
+    // them; an INNER / OUTER call: the PLAIN riders and the fused end-point frames) and the three-segment frames of a FUSED OUTER
+    // call; both kernels decide per frame ON THE DEVICE from the coefficients, the host-side counts below only attribute the work.
+    //   default: calls it can run ALONE (PLAIN, fused OUTER) from 2048 keys up — S = 4096: plain 648 -> 588 us, outer 1293 -> see
+    //   profiles/r03_attn_notes.txt; at S = 1024 its one workgroup per CU cannot hide the per-workgroup start-up (-12 %).
+    //   ATTN_V2 = 0 never; 1 wherever supported (tests) — calls it cannot run alone (INNER, pure OUTER) are then split: single-segment
+    //   frames here, the others on aid_attn_kernel in a second launch.
     const int n_single = a.mode == AID_MODE_PLAIN ? a.n_frames : a.n_plain + ((a.fused && a.n_frames - a.n_plain >= 2) ? 2 : 0);
-    // The ping-pong kernel (aid_attn_pp.hip) takes calls made of single-segment frames only, from 2048 keys up: +10 % at S = 4096;
-    // at S = 1024 its one workgroup per CU cannot hide the per-workgroup start-up (-12 %), and splitting a mixed INNER / OUTER
-    // call into two launches loses more than the riders gain (profiles/r03_attn_notes.txt).  Knob ATTN_V2: 0 never, 1 wherever
-    // it is supported (tests), default = this rule.
+    const bool alone = a.mode == AID_MODE_PLAIN || (a.mode == AID_MODE_OUTER && a.fused && a.l % 512 == 0);     // (segments of whole 8-tile trips)
     const int v2 = aid::tune(aid::TUNE_ATTN_V2);
-    const bool use_pp = n_single > 0 && aid::attn_pp_supported(a) &&
-                        (v2 == 1 || (v2 < 0 && n_single == a.n_frames && a.l >= 2048));
+    const bool use_pp = aid::attn_pp_supported(a) && (alone || n_single > 0) &&
+                        (v2 == 1 || (v2 < 0 && alone && a.l >= 2048));
     if (use_pp) {
         char nm[64];
-        snprintf(nm, sizeof(nm), "aid_attn_pp<%s,d64>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16");
-        const double f1 = per_seg * n_single;
-        ProfScope ps(static_cast<hipStream_t>(stream), nm, f1, bytes * n_single / a.n_frames, f1);
-        e = aid::attn_pp_launch(a, static_cast<hipStream_t>(stream));
-        g_variant = "aid_attn_pp<d64>";
+        snprintf(nm, sizeof(nm), "aid_attn_pp<%s,d64%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16",
+                 a.mode == AID_MODE_PLAIN ? "" : alone ? ",outer" : ",riders");
+        const double f1 = alone ? flops : per_seg * n_single;
+        ProfScope ps(static_cast<hipStream_t>(stream), nm, f1, alone ? bytes : bytes * n_single / a.n_frames,
+                     alone ? flops_exec : f1);
+        e = aid::attn_pp_launch(a, static_cast<hipStream_t>(stream), alone);
+        g_variant = alone && a.mode != AID_MODE_PLAIN ? "aid_attn_pp<d64,outer>" : "aid_attn_pp<d64>";
     }
-    if (e == hipSuccess && !(use_pp && a.mode == AID_MODE_PLAIN)) {
+    if (e == hipSuccess && !(use_pp && alone)) {
         const char* nm = aid::attn_variant_name(a);
         const double fa = use_pp ? flops - per_seg * n_single : flops;
         const double fx = use_pp ? flops_exec - per_seg * n_single : flops_exec;

@@ -86,28 +86,6 @@ struct OState {
     f32x16 cn[QB];                      // -m in all 16 registers (C operand of the first MFMA), kept when PERSIST_C
 };
 
-// Block -> logical id for a launch that mixes interpolated frames (up to three key segments per q block) with PLAIN riders
-// (one segment): inside every XCD's contiguous range the heavy workgroups are listed FIRST, so a range never ends on a
-// late-started three-segment workgroup running alone (S = 1024 OUTER with 7 + 7 frames: a workgroup lives 10 - 40 us of a
-// 180 us launch).  `per` = workgroups per head, the first `na` of them heavy; a stable partition of the XCD's range, so
-// neighbours still share K / V^T in that XCD's L2.  Any (na, per) gives a bijection: a wrong hint only costs balance.
-__device__ __forceinline__ int heavy_first(int bid, int nblocks, int na, int per) {
-    constexpr int NX = 8;
-    const int q = nblocks / NX, r = nblocks % NX;
-    const int x = bid % NX, j = bid / NX;
-    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    const int end = base + q + (x < r ? 1 : 0);
-    const int nb = per - na;
-    const int a0 = (base / per) * na + min(base % per, na);         // heavy ids below `base`
-    const int a1 = (end / per) * na + min(end % per, na);
-    if (j < a1 - a0) {
-        const int t = a0 + j;
-        return (t / na) * per + t % na;
-    }
-    const int t = (base - a0) + (j - (a1 - a0));                     // light ids below `base`, plus the position among the lights
-    return (t / nb) * per + na + t % nb;
-}
-
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 __device__ __forceinline__ Rsrc make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);

@@ -30,12 +30,14 @@ namespace aid {
 namespace {
 
 constexpr int PKT = 64;                 // keys per tile
-constexpr int PSTAGE = 16384;           // bytes per ring stage: K tile [64 keys][128 B] + V^T tile [64 rows][128 B]
+constexpr int PTILE = 8192;             // bytes per tile: K [64 keys][128 B] or V^T [64 channels][128 B]
+constexpr int PSTAGE = 2 * PTILE;       // bytes per ring stage (K tile + V^T tile)
 constexpr int PNS = 8;                  // ring depth (128 KB)
 
 struct AttnPPParams {
     AidAttnArgs a;
     int32_t nqb;                        // 256-row q blocks per (frame, head)
+    int32_t multi;                      // 1: this launch also runs the three-segment frames of a fused OUTER call (it is the only launch)
     float   c2;                         // softmax_scale * log2(e)
     int32_t abl;                        // development builds (-DAID_ABLATIONS): timing ablations, results are garbage
 };
@@ -66,7 +68,11 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const int grp = wave >> 2;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);           // [head][frame][q block]: a (frame, head)'s blocks share an L2
+    // [head][frame][q block]: a (frame, head)'s blocks share an L2; three-segment frames first inside every XCD's range
+    const int n_heavy = a.n_frames - a.n_plain;
+    const int lid = (p.multi && a.n_plain > 0 && n_heavy > 0)
+                        ? heavy_first(blockIdx.x, gridDim.x, n_heavy * p.nqb, a.n_frames * p.nqb)
+                        : xcd_remap(blockIdx.x, gridDim.x);
     const int qb = lid % p.nqb;
     const int fr = (lid / p.nqb) % a.n_frames;
     const int h = lid / (p.nqb * a.n_frames);
@@ -75,10 +81,27 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // Frames with more than one key segment (interior frames of an INNER / OUTER call) belong to aid_attn_kernel, which is
     // launched next to this kernel and skips the frames this one runs: BOTH evaluate the same predicate on the device
     // coefficients, so the split is exact whatever the host-side hints say.
+    // A fused OUTER frame that is not single walks own keys -> begin keys -> end keys (reference interpolation.py:626-664: two
+    // softmaxes over [own ; begin] and [own ; end], outputs mixed (1 - c) : c).  The state after the own segment serves both: it is
+    // PARKED in registers (po / pl / pm) when the begin segment starts and swapped back in when the end segment starts, while the
+    // parked registers take the finished begin side.  c == 0 / c == 1 (not an end-point row): the zero-weighted side is dropped.
+    int nseg = 1, seg1 = 0, seg2 = 0;                           // key / value rows of segments 1 and 2 (segment 0 = kvf)
+    const int row_b = a.begin, row_e = a.end;
+    float w_b = 0.f, w_e = 1.f;
+    bool two_sides = false;
     if (a.mode != AID_MODE_PLAIN) {
         const float cf = a.coef[fr];
-        const bool single = cf < 0.f || (a.fused && ((cf == 0.f && kvf == a.begin) || (cf == 1.f && kvf == a.end)));
-        if (!single) return;
+        const bool single = cf < 0.f || (a.fused && ((cf == 0.f && kvf == row_b) || (cf == 1.f && kvf == row_e)));
+        if (!single) {
+            if (!(p.multi && a.mode == AID_MODE_OUTER && a.fused)) return;
+            // (arithmetic, not `c == 1 ? a.end : a.begin`: a select between two FIELDS of the by-value argument struct becomes a
+            //  select between their addresses and hipcc then keeps the whole struct in scratch)
+            two_sides = cf != 0.f && cf != 1.f;
+            nseg = two_sides ? 3 : 2;
+            seg1 = row_b + (cf == 1.f ? 1 : 0) * (row_e - row_b);
+            seg2 = row_e;
+            if (two_sides) { w_b = 1.f - cf; w_e = cf; }
+        }
     }
 
     // ---- Q fragments (B operand of the swapped product) -----------------------------------------
@@ -102,47 +125,56 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     for (int e = 0; e < 8; ++e) onesf[e] = (l31 == 0) ? (T)1.0f : (T)0.0f;
 
     // ---- DMA addressing: this wave's piece (8 rows x 128 B) of every K tile and of every V^T tile ------------
-    const T* Kg = reinterpret_cast<const T*>(a.k) + (int64_t)kvf * a.k_fs + h * D;
-    const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)kvf * a.vt_fs + (int64_t)(h * D) * a.ldvt;
+    // one descriptor per tensor (this head's columns / rows); the key / value ROW of a segment goes into the scalar offset
+    // (attn_pp_supported: the tensors are below 2 GB)
+    const T* Kg = reinterpret_cast<const T*>(a.k) + h * D;
+    const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)(h * D) * a.ldvt;
     const Rsrc rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Kg), 0, 0x7fffffff, 0x00020000);
     const Rsrc rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Vg), 0, 0x7fffffff, 0x00020000);
+    const int nt = a.l / PKT;                                   // tiles per segment
+    const int NT = nseg * nt;                                   // tiles of this workgroup's stream
+    const int ks0 = kvf * (int)a.k_fs * 2, ks1 = seg1 * (int)a.k_fs * 2, ks2 = seg2 * (int)a.k_fs * 2;
+    const int vs0 = kvf * (int)a.vt_fs * 2, vs1 = seg1 * (int)a.vt_fs * 2, vs2 = seg2 * (int)a.vt_fs * 2;
     const int prow = 8 * wave + (lane >> 3);                    // tile row this lane fetches
     const int pch = (lane & 7) ^ ((prow >> 1) & 7);             // logical 16-B chunk stored at slot lane & 7 (XOR swizzle)
     const int kvo = prow * (a.ldk * 2) + pch * 16;              // + key0 * ldk * 2 (scalar)
     const int vvo = prow * (a.ldvt * 2) + pch * 16;             // + key0 * 2       (scalar)
-    auto dma_tile = [&](int t) __attribute__((always_inline)) {
-        char* st = smem + (t & (PNS - 1)) * PSTAGE + wave * 1024;        // t & 3 is a constant wherever the caller's is (main loop)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)st, 16, kvo, t * PKT * a.ldk * 2, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(st + 8192), 16, vvo, t * PKT * 2, 0, 0);
+    auto dma_tile = [&](int g) __attribute__((always_inline)) {     // g: tile of the stream = segment g / nt, tile g % nt of it
+        char* st = smem + (g & (PNS - 1)) * PTILE + wave * 1024;         // g & 7 is a constant wherever the caller's is (main loop)
+        const int sg = (g >= nt) + (g >= 2 * nt);
+        const int t = g - sg * nt;
+        // (arithmetic on values: `sg == 0 ? ks0 : ...` is a select between ADDRESSES of captured variables and keeps them in scratch)
+        const int ko = ks0 + (sg >= 1 ? ks1 - ks0 : 0) + (sg >= 2 ? ks2 - ks1 : 0);
+        const int vo = vs0 + (sg >= 1 ? vs1 - vs0 : 0) + (sg >= 2 ? vs2 - vs1 : 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)st, 16, kvo, ko + t * PKT * a.ldk * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(st + PNS * PTILE), 16, vvo, vo + t * PKT * 2, 0, 0);
     };
 
     // ---- fragment read offsets: K rows with key bits 2 <-> 3 swapped (so P comes out in B-operand order), V^T rows = channels
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
     const int kx = hi ^ ((krow >> 1) & 7), vx = hi ^ ((l31 >> 1) & 7);      // swz(r + 32) == swz(r)
-    const int koff = krow * 128, voff = 8192 + l31 * 128;
-    // per-lane LDS address of k-step ks inside ring half 0 / 1; stage (within the half) and block go into the 16-bit offset field
-    int kad[2][4], vad[2][4];
+    const int koff = krow * 128, voff = PNS * PTILE + l31 * 128;
+    // LDS: the K tiles of the eight stages in [0, 64 KB), the V^T tiles in [64 KB, 128 KB): per-lane address of k-step ks in the
+    // register (< 4 KB, resp. 64 KB + < 4 KB), stage * 8 KB + block * 4 KB in the 16-bit offset field (<= 61440)
+    int kad[4], vad[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        kad[0][ks] = koff + (((2 * ks) ^ kx) << 4);
-        vad[0][ks] = voff + (((2 * ks) ^ vx) << 4);
-        kad[1][ks] = kad[0][ks] + 4 * PSTAGE;
-        vad[1][ks] = vad[0][ks] + 4 * PSTAGE;
+        kad[ks] = koff + (((2 * ks) ^ kx) << 4);
+        vad[ks] = voff + (((2 * ks) ^ vx) << 4);
     }
 
     // ---- online-softmax state -----------------------------------------------------------------------
     float m = 0.f;
     bool fresh = true;
     f32x16 o[2], ol, sc[2];
-    f32x16 cneg;                        // -m as an accumulator block: the C operand of a tile's first score MFMAs, rebuilt on a rescale only
     T8 pf[4];
+    f32x16 po[2];                       // parked: O of the own-keys state while the begin side runs, then the finished begin side
+    float pl = 0.f, pm = 0.f;           // parked row sum (this lane's register of the row-sum block) and row reference
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; cneg[r] = 0.f; }
-    asm volatile("" : "+v"(cneg));
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; po[0][r] = 0.f; po[1][r] = 0.f; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) pf[i] = zero8<T>();
 
-    const int nt = a.l / PKT;
 #ifdef AID_ABLATIONS
     // 16: slot timing — shader cycles of [V work | wait at the barrier behind it | M work | wait at the barrier behind it], summed over the
     // tiles and written over the output rows (lane 0 of every wave: four floats = cycles per tile)
@@ -165,10 +197,10 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // operand fragments: kf = K(t + 1) for S(t + 1), vf = V^T(t) for O += V^T(t) P(t)^T, all four k-steps each
     T8 kf[4][2], vf[4][2];
     auto lds_k = [&](int st, int ks, int b) __attribute__((always_inline)) {           // st: ring stage, a constant wherever it matters
-        return *reinterpret_cast<const T8*>(smem + kad[st >> 2][ks] + ((st & 3) * PSTAGE + b * 4096));
+        return *reinterpret_cast<const T8*>(smem + kad[ks] + (st * PTILE + b * 4096));
     };
     auto lds_v = [&](int st, int kk, int d) __attribute__((always_inline)) {
-        return *reinterpret_cast<const T8*>(smem + vad[st >> 2][kk] + ((st & 3) * PSTAGE + d * 4096));
+        return *reinterpret_cast<const T8*>(smem + vad[kk] + (st * PTILE + d * 4096));
     };
     auto pin = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
 
@@ -182,6 +214,9 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             return;
         }
 #endif
+        f32x16 cneg;                                            // -m as an accumulator block: C operand of the first score MFMAs
+#pragma unroll                                                  // (kept across slots it measured the same and costs 16 registers)
+        for (int r = 0; r < 16; ++r) cneg[r] = -m;
         pin();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -214,12 +249,12 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         else             wait_vm<0>();
     };
     auto vslot = [&](int t) __attribute__((always_inline)) {
-        const bool issue = t + LEAD < nt;
+        const bool issue = t + LEAD < NT;
 #ifdef AID_ABLATIONS
         if (p.abl & 1) {                                        // 1: no VALU work in the V slot
             if (!(p.abl & 2) && issue) dma_tile(t + LEAD);
             fresh = false;
-            retire(nt - 4 - t);
+            retire(NT - 4 - t);
             return;
         }
 #endif
@@ -242,9 +277,6 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             const float alpha = __builtin_amdgcn_exp2f(-shift);
             m += shift;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cneg[r] = -m;
-            asm volatile("" : "+v"(cneg));                      // (opaque: keeps hipcc from rebuilding the block in every M slot)
-#pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; ol[r] *= alpha; }
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -262,7 +294,36 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
                 pf[2 * b + u] = cvt8<T>(pv);
             }
-        retire(nt - 4 - t);
+        retire(NT - 4 - t);
+    };
+
+    // Segment boundaries of a two-sided frame.  S(t) of the next segment's first tile is in `sc` and PV(t - 1) closed the segment
+    // before it: O, l, m are at rest.
+    auto park = [&]() __attribute__((always_inline)) {          // own keys done: park the state, the begin side continues on it
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { po[0][r] = o[0][r]; po[1][r] = o[1][r]; }
+        pl = ol[0];
+        pm = m;
+    };
+    auto swap_sides = [&]() __attribute__((always_inline)) {    // begin side done: keep (1 - c) O_b / l_b, resume the own-keys state
+        const float lv = ol[0];
+        const float lrow = hi ? other_half(lv) : lv;            // the row sum sits at the lanes of half 0
+        const float wb = w_b / lrow;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float rb = o[d][r] * wb;
+                o[d][r] = po[d][r];
+                po[d][r] = rb;
+            }
+        ol[0] = pl;                                             // (the other registers of the row-sum block are zero in every state)
+        const float back = m - pm;                              // S(t) was formed against the begin side's reference (>= the parked one)
+        m = pm;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[b][r] += back;
     };
 
     // fence between a slot's last MFMAs and the VALU code of the next slot that reads their results (20 wait states; the hazard
@@ -283,47 +344,57 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // ---- prologue: pieces of tiles 0 .. 5 requested, 0 .. 2 retired and published; S(0); fragments of K(1) ----------------
 #pragma unroll
     for (int t = 0; t < LEAD; ++t)
-        if (t < nt) dma_tile(t);
-    retire(nt - 3);
+        if (t < NT) dma_tile(t);
+    retire(NT - 3);
     slot_barrier();
     if (grp == 1) slot_barrier();                               // the second group runs one barrier behind
 #pragma unroll
     for (int i = 0; i < 8; ++i) kf[i >> 1][i & 1] = lds_k(0, i >> 1, i & 1);
+    f32x16 zacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zacc[r] = 0.f;
 #ifdef AID_ABLATIONS
     if (!(p.abl & 4))
 #endif
     {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sc[i & 1] = mfma32(kf[i >> 1][i & 1], qf[i >> 1], (i >> 1) ? sc[i & 1] : cneg);
+        for (int i = 0; i < 8; ++i) sc[i & 1] = mfma32(kf[i >> 1][i & 1], qf[i >> 1], (i >> 1) ? sc[i & 1] : zacc);      // m = 0
         pin();
 #pragma unroll
         for (int i = 0; i < 8; ++i) kf[i >> 1][i & 1] = lds_k(1, i >> 1, i & 1);      // nt >= 2
     }
     settle();
     slot_barrier();
-    // eight tiles per trip: t & 7 — the ring stage of every DMA and fragment read — is a compile-time constant in each copy
-    for (int t8 = 0; t8 + 1 < nt; t8 += 8) {
+    // One pass per key segment (`nounroll`: one copy of the body); inside, eight tiles per trip: t & 7 — the ring stage of every DMA
+    // and fragment read — is a compile-time constant in each copy (segments of a multi-segment frame are multiples of eight tiles).
+#pragma nounroll
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+        if (two_sides && sgi == 1) park();
+        if (two_sides && sgi == 2) swap_sides();
+        const int t_end = min((sgi + 1) * nt, NT - 1);          // V(t) + M(t + 1) for the tiles t of this segment; the stream's last
+        for (int t8 = sgi * nt; t8 < t_end; t8 += 8) {          // tile is finished behind the loop
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int t = t8 + j;
-            if (t + 1 >= nt) break;
-            PP_STAMP(3);
-            vslot(t);
-            PP_STAMP(0);
-            slot_barrier();
-            PP_STAMP(1);
-            mslot(j, (j + 2) & 7);                              // (the K(t + 2) reads past the last tile fetch stale ring bytes, unused)
-            settle();
-            PP_STAMP(2);
-            slot_barrier();
+            for (int j = 0; j < 8; ++j) {
+                const int t = t8 + j;
+                if (t >= t_end) break;
+                PP_STAMP(3);
+                vslot(t);
+                PP_STAMP(0);
+                slot_barrier();
+                PP_STAMP(1);
+                mslot(j, (j + 2) & 7);                          // (the K(t + 2) reads past the last tile fetch stale ring bytes, unused)
+                settle();
+                PP_STAMP(2);
+                slot_barrier();
+            }
         }
     }
-    vslot(nt - 1);
+    vslot(NT - 1);
     slot_barrier();
-    {                                                           // O += V^T(nt - 1) P(nt - 1)^T
-        const int so = ((nt - 1) & 7) * PSTAGE;
+    {                                                           // O += V^T(NT - 1) P(NT - 1)^T
+        const int so = ((NT - 1) & 7) * PTILE;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) vf[i >> 1][i & 1] = *reinterpret_cast<const T8*>(smem + vad[0][i >> 1] + so + (i & 1) * 4096);
+        for (int i = 0; i < 8; ++i) vf[i >> 1][i & 1] = *reinterpret_cast<const T8*>(smem + vad[i >> 1] + so + (i & 1) * 4096);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -340,17 +411,17 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     if (p.abl & 16) {
         if (lane == 0 && q0 < a.s) {
             float* dbg = reinterpret_cast<float*>(reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q0 * a.ldo + h * D);
-            for (int i = 0; i < 4; ++i) dbg[i] = tacc[i] / (float)(nt - 1);
+            for (int i = 0; i < 4; ++i) dbg[i] = tacc[i] / (float)(NT - 1);
         }
         return;
     }
 #endif
     const float lv = ol[0];
     const float partner = other_half(lv);                       // the row sum sits at the lanes of half 0
-    const float inv = 1.f / (hi ? partner : lv);
+    const float inv = w_e / (hi ? partner : lv);                // (w_e = 1 unless this frame mixes two sides)
     const int q = q0 + l31;
     if (q < a.s) {
-        const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f) * inv;
+        const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
         T* orow = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q * a.ldo + h * D;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -359,7 +430,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 const int dv = 32 * d + 8 * g + 4 * hi;
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * osc;
+                for (int e = 0; e < 4; ++e) v[e] = (o[d][4 * g + e] * inv + po[d][4 * g + e]) * osc;      // po: the begin side, or zero
                 if (a.accumulate) v += up4<T>(*reinterpret_cast<const T4*>(orow + dv));
                 *reinterpret_cast<T4*>(orow + dv) = cvt4<T>(v);
             }
@@ -370,12 +441,14 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 
 // May the ping-pong kernel run the single-segment frames of this call?  d = 64, whole 64-key tiles, at least two of them.
 bool attn_pp_supported(const AidAttnArgs& a) {
-    return a.d == 64 && a.l % PKT == 0 && a.l >= 2 * PKT && a.ldk % 8 == 0 && a.ldvt % 8 == 0;
+    const int64_t kb = (int64_t)a.n_kv * a.k_fs * 2, vb = (int64_t)a.n_kv * a.vt_fs * 2;    // segment rows ride in 32-bit scalar offsets
+    return a.d == 64 && a.l % PKT == 0 && a.l >= 2 * PKT && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && kb < (1ll << 31) && vb < (1ll << 31);
 }
 
-hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream) {
+hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) {
     AttnPPParams p;
     p.a = a;
+    p.multi = multi ? 1 : 0;
     p.nqb = (a.s + 255) / 256;
     p.c2 = a.softmax_scale * 1.4426950408889634f;
     p.abl = tune(TUNE_ATTN_RES_CHUNKS) > 100 ? tune(TUNE_ATTN_RES_CHUNKS) - 100 : 0;      // development builds only

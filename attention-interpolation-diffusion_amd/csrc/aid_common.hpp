@@ -89,6 +89,29 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return base + j;
 }
 
+// Block -> logical id for a launch that mixes interpolated frames (up to three key segments per q block) with PLAIN riders
+// (one segment): inside every XCD's contiguous range the heavy workgroups are listed FIRST, so a range never ends on a
+// late-started three-segment workgroup running alone (S = 1024 OUTER with 7 + 7 frames: a workgroup lives 10 - 40 us of a
+// 180 us launch).  `per` = workgroups per head, the first `na` of them heavy; a stable partition of the XCD's range, so
+// neighbours still share K / V^T in that XCD's L2.  Any (na, per) gives a bijection: a wrong hint only costs balance.
+__device__ __forceinline__ int heavy_first(int bid, int nblocks, int na, int per) {
+    constexpr int NX = 8;
+    const int q = nblocks / NX, r = nblocks % NX;
+    const int x = bid % NX, j = bid / NX;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    const int end = base + q + (x < r ? 1 : 0);
+    const int nb = per - na;
+    const int a0 = (base / per) * na + min(base % per, na);         // heavy ids below `base`
+    const int a1 = (end / per) * na + min(end % per, na);
+    if (j < a1 - a0) {
+        const int t = a0 + j;
+        return (t / na) * per + t % na;
+    }
+    const int t = (base - a0) + (j - (a1 - a0));                     // light ids below `base`, plus the position among the lights
+    return (t / nb) * per + na + t % nb;
+}
+
+
 // Host side: state that is per DEVICE, not per process (hipFuncSetAttribute applies to the current device only, and a
 // process may drive several GPUs).  slot() returns the current device's entry, or nullptr when there is no device.
 template <typename V>
