@@ -307,7 +307,8 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     };
     auto swap_sides = [&]() __attribute__((always_inline)) {    // begin side done: keep (1 - c) O_b / l_b, resume the own-keys state
         const float lv = ol[0];
-        const float lrow = hi ? other_half(lv) : lv;            // the row sum sits at the lanes of half 0
+        const float partner = other_half(lv);                   // (all lanes take part in the exchange: not inside the `?:`)
+        const float lrow = hi ? partner : lv;                   // the row sum sits at the lanes of half 0
         const float wb = w_b / lrow;
 #pragma unroll
         for (int d = 0; d < 2; ++d)

@@ -1,8 +1,9 @@
-"""GPU: the ping-pong attention kernel (csrc/aid_attn_pp.hip: d = 64, one key segment per frame, whole 64-key tiles; a built
-variant, enabled by the tuning knob ATTN_V2 = 1 — it measured +3 % / -12 % against the default kernel, profiles/r03_attn_notes.txt)
-against the fp64 oracle and against the program-order kernel.  A PLAIN call runs on it alone;
-in an INNER / OUTER call it takes the PLAIN riders and the fused end-point frames while aid_attn_kernel runs the interior
-frames next to it — both kernels split the frames by the same predicate on the DEVICE coefficients."""
+"""GPU: the ping-pong attention kernel (csrc/aid_attn_pp.hip: d = 64, whole 64-key tiles; default for PLAIN and fused OUTER calls
+from 2048 keys up, forced everywhere it is supported by the tuning knob ATTN_V2 = 1, profiles/r03_attn_notes.txt) against the fp64
+oracle and against the program-order kernel.  A PLAIN call and a fused OUTER call whose key count is a multiple of 512 run on it
+alone (three-segment frames: own -> begin -> end keys as one tile stream, the own-keys state parked in registers); any other
+INNER / OUTER call is split — PLAIN riders and fused end-point frames here, the others on aid_attn_kernel in a second launch — and
+both kernels split the frames by the same predicate on the DEVICE coefficients."""
 import numpy as np
 import pytest
 import torch
@@ -70,6 +71,59 @@ def test_mixed_call_splits_the_frames_between_the_two_kernels(dtype, mode, fused
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("l,s,riders", [(512, 200, 7), (1024, 96, 0), (512, 33, 3)], ids=["l512", "l1024", "l512_s33"])
+def test_fused_outer_call_runs_alone_on_the_pingpong_kernel(dtype, l, s, riders, tuning):
+    """Three-segment frames (own -> begin -> end keys, own-keys state parked and swapped back), end points, frames with a coefficient
+    of exactly 0 / 1 that are NOT the end-point rows (two segments, the zero-weighted side dropped) and PLAIN riders in ONE launch."""
+    tuning("ATTN_V2", 1)
+    n, h = 7, 2
+    q, k, v, vt = _inputs(n + riders, s, l, h, dtype, seed=l + s)
+    coef = torch.from_numpy(O.beta_coefs(n, 3, 3)).float()
+    coef[1], coef[5] = 0.0, 1.0                                 # interior rows with end-point coefficients
+    cd = torch.cat([coef.to(dtype).float(), -torch.ones(riders)])
+    args = dict(l=l, mode="outer", fused=True, coef=cd.to(DEV), begin=0, end=n - 1, n_plain=riders)
+    o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, **args)
+    assert ops.last_attn_variant() == "aid_attn_pp<d64,outer>"
+    q64, k64, v64 = to_np64(q), to_np64(k), to_np64(v)
+    ref = O.attn_core(q64[:n], k64[:n], v64[:n], h, 64 ** -0.5, "outer", True, coef.to(dtype).float().numpy())
+    if riders:
+        ref = np.concatenate([ref, O.attn_core(q64[n:], k64[n:], v64[n:], h, 64 ** -0.5, "plain", False, None)])
+    for f in range(n + riders):
+        assert rel_l2(to_np64(o[f]), ref[f]) < TOL[dtype], f
+    assert torch.isfinite(o).all() and worst(to_np64(o), ref) < WORST[dtype]
+    tuning("ATTN_V2", 0)                                        # the program-order kernel on the same call
+    o_old = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, **args)
+    assert "aid_attn_pp" not in ops.last_attn_variant() and rel_l2(to_np64(o), to_np64(o_old)) < TOL[dtype]
+    tuning("ATTN_V2", 1)
+    assert torch.equal(ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, **args), o)          # deterministic
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+def test_fused_outer_rescales_inside_the_begin_and_end_segments(dtype, tuning):
+    """Spiked keys in the END-POINT frames: the begin side's row reference leaves the parked one behind (the first end tile's scores
+    are shifted back by the difference), then the end side raises it again; accumulate + scales on the three-segment path."""
+    tuning("ATTN_V2", 1)
+    n, s, l, h = 4, 64, 512, 1
+    q, k, v, vt = _inputs(n, s, l, h, dtype, seed=11)
+    k[0, 70] = q[1, 5] * 5.0                                    # begin keys: spikes for rows of the interior frames
+    k[0, 400] = q[2, 9] * 6.0
+    k[n - 1, 3] = q[1, 5] * 4.0                                 # end keys: first tile and last tile
+    k[n - 1, 511] = q[2, 40] * 7.0
+    k[1, 200] = q[1, 17] * 5.0                                  # own keys
+    vt = v.transpose(1, 2).contiguous()
+    coef = torch.tensor([0.0, 0.3, 0.8, 1.0])
+    fs = torch.tensor([0.5, 1.0, 2.0, 0.25])
+    base = torch.randn(n, s, h * 64).to(dtype)
+    out = base.clone().to(DEV)
+    ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="outer", fused=True, coef=coef.to(dtype).float().to(DEV), begin=0,
+                 end=n - 1, frame_scale=fs.to(DEV), out_scale=0.7, accumulate=True, out=out)
+    assert ops.last_attn_variant() == "aid_attn_pp<d64,outer>"
+    ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, 64 ** -0.5, "outer", True, coef.to(dtype).float().numpy())
+    ref = to_np64(base) + 0.7 * fs.numpy()[:, None, None] * ref
+    assert np.isfinite(to_np64(out)).all() and rel_l2(to_np64(out), ref) < TOL[dtype] and worst(to_np64(out), ref) < WORST[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
 def test_forced_rescale_on_the_pingpong_kernel(dtype, tuning):
     """Spiked keys late in the sequence push the row reference up after many tiles (the rare branch: O, its row-sum row and the
     tile's arguments are rescaled in the VALU slot, between PV(t - 1) and PV(t))."""
@@ -105,6 +159,18 @@ def test_accumulate_scales_kv_map_and_determinism(tuning):
         o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="plain")
         outs.append(o.clone())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+def test_default_rule_picks_the_pingpong_kernel_from_2048_keys(tuning):
+    """No knob: PLAIN and fused OUTER calls with >= 2048 keys run on the ping-pong kernel, shorter ones and INNER calls do not."""
+    dtype, h = torch.bfloat16, 1
+    for l, mode, fused, want in ((2048, "plain", False, True), (1024, "plain", False, False), (2048, "outer", True, True),
+                                 (2048, "outer", False, False), (2048, "inner", True, False), (2112, "outer", True, False)):
+        q, k, v, vt = _inputs(3, 32, l, h, dtype, seed=l)
+        coef = torch.tensor([0.0, 0.5, 1.0])
+        ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused,
+                     coef=None if mode == "plain" else coef.to(DEV), begin=0, end=2)
+        assert ("aid_attn_pp" in ops.last_attn_variant()) == want, (l, mode, fused, ops.last_attn_variant())
 
 
 def test_full_size_sdxl_levels_sampled_rows(tuning):
