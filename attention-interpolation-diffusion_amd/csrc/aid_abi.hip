@@ -359,15 +359,16 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     // d = 64, whole key tiles: the ping-pong kernel (aid_attn_pp.hip).  It runs the frames with ONE key segment (a PLAIN call: all of
     // them; an INNER / OUTER call: the PLAIN riders and the fused end-point frames) and the three-segment frames of a FUSED OUTER
     // call; both kernels decide per frame ON THE DEVICE from the coefficients, the host-side counts below only attribute the work.
-    //   default: calls it can run ALONE (PLAIN, fused OUTER) from 2048 keys up — S = 4096: plain 648 -> 588 us, outer 1293 -> see
-    //   profiles/r03_attn_notes.txt; at S = 1024 its one workgroup per CU cannot hide the per-workgroup start-up (-12 %).
+    //   default: calls it can run ALONE — PLAIN from 2048 keys, fused OUTER from 1024 (S = 4096: plain 648 -> 588 us, outer 1160 -> 1078;
+    //   S = 1024: outer 163.5 -> 161.1, but plain 93 -> 110: its one workgroup per CU cannot hide the per-workgroup start-up of a
+    //   16-tile stream; profiles/r03_attn_notes.txt).
     //   ATTN_V2 = 0 never; 1 wherever supported (tests) — calls it cannot run alone (INNER, pure OUTER) are then split: single-segment
     //   frames here, the others on aid_attn_kernel in a second launch.
     const int n_single = a.mode == AID_MODE_PLAIN ? a.n_frames : a.n_plain + ((a.fused && a.n_frames - a.n_plain >= 2) ? 2 : 0);
     const bool alone = a.mode == AID_MODE_PLAIN || (a.mode == AID_MODE_OUTER && a.fused && a.l % 512 == 0);     // (segments of whole 8-tile trips)
     const int v2 = aid::tune(aid::TUNE_ATTN_V2);
     const bool use_pp = aid::attn_pp_supported(a) && (alone || n_single > 0) &&
-                        (v2 == 1 || (v2 < 0 && alone && a.l >= 2048));
+                        (v2 == 1 || (v2 < 0 && alone && a.l >= (a.mode == AID_MODE_PLAIN ? 2048 : 1024)));
     if (use_pp) {
         char nm[64];
         snprintf(nm, sizeof(nm), "aid_attn_pp<%s,d64%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16",

@@ -161,11 +161,13 @@ def test_accumulate_scales_kv_map_and_determinism(tuning):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
-def test_default_rule_picks_the_pingpong_kernel_from_2048_keys(tuning):
-    """No knob: PLAIN and fused OUTER calls with >= 2048 keys run on the ping-pong kernel, shorter ones and INNER calls do not."""
+def test_default_rule_for_the_pingpong_kernel(tuning):
+    """No knob: PLAIN calls from 2048 keys and fused OUTER calls from 1024 (multiples of 512) run on the ping-pong kernel; shorter
+    ones, pure OUTER and INNER calls do not."""
     dtype, h = torch.bfloat16, 1
     for l, mode, fused, want in ((2048, "plain", False, True), (1024, "plain", False, False), (2048, "outer", True, True),
-                                 (2048, "outer", False, False), (2048, "inner", True, False), (2112, "outer", True, False)):
+                                 (1024, "outer", True, True), (512, "outer", True, False), (2048, "outer", False, False),
+                                 (2048, "inner", True, False), (2112, "outer", True, False)):
         q, k, v, vt = _inputs(3, 32, l, h, dtype, seed=l)
         coef = torch.tensor([0.0, 0.5, 1.0])
         ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused,

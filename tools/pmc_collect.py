@@ -43,6 +43,8 @@ def bench_name(sym):
             return f"aid_attn<{dt},d{m.group(1)},{MODES[m.group(2)]},res>"
         sfx = ",qb2" if m.group(4) == "2" else ",pipe" if m.group(5) == "1" else ""
         return f"aid_attn<{dt},d{m.group(1)},{MODES[m.group(2)]},nw{m.group(3)}{sfx}>"
+    if "aid_attn_pp_kernel" in sym:                     # one device symbol behind aid_attn_pp<dt,d64> and aid_attn_pp<dt,d64,outer>
+        return f"aid_attn_pp<{dt},d64>"
     m = re.search(r"aid_attn_short_kernelIDF16b?_?Li(\d+)ELi(\d)", sym)
     if m:
         return f"aid_attn_short<{dt},d{m.group(1)},{MODES[m.group(2)]}>"
