@@ -480,11 +480,14 @@ def main():
         # (replicated end points make the ideal speed-up n_total / max_local_batch, not the rank count)
         result["config"]["busiest_rank_local_frames_per_s"] = mlb / (tm["ms_per_step"] * 50.0 / 1000.0)
 
-    if rank == 0 and not args.no_roofline:
-        # N > 1: rank 0's LOCAL batch (no collective inside a step, so one rank can time its kernels alone)
-        result["roofline"] = roofline_object(roofline_pass(loop, aid_amd, torch), wl["stack"])
-        if world > 1:
-            result["roofline"]["scope"] = f"rank 0 of {world}: local batch of {shard.n_local} frames"
+    if not args.no_roofline and (rank == 0 or args.endpoints == "exchange"):
+        # N > 1: rank 0's LOCAL batch.  Replicated end points: no collective inside a step, so rank 0 times its kernels alone;
+        # the exchange layout broadcasts per layer, so every rank walks the profiled steps and rank 0 reports
+        prof = roofline_pass(loop, aid_amd, torch)
+        if rank == 0:
+            result["roofline"] = roofline_object(prof, wl["stack"])
+            if world > 1:
+                result["roofline"]["scope"] = f"rank 0 of {world}: local batch of {shard.n_local} frames"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and name != "ip":
         result["cpu_baseline"] = cpu_baseline(wl["stack"], wl["n_total"], wl["early"], steps, args.warmup_ratio)
     if rank == 0 and world == 1 and name == "sdxl" and args.workload == "auto" and not args.model and not args.no_also:
