@@ -356,28 +356,30 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     const double flops_exec = a.seg_executed > 0 ? per_seg * a.seg_executed : flops;
     const double bytes = 2.0 * (2.0 * a.n_frames * a.s * c + 2.0 * a.n_kv * a.l * c);
     hipError_t e = hipSuccess;
-    // d = 64, whole key tiles: the ping-pong kernel (aid_attn_pp.hip).  It runs the frames with ONE key segment (a PLAIN call: all of
-    // them; an INNER / OUTER call: the PLAIN riders and the fused end-point frames) and the three-segment frames of a FUSED OUTER
-    // call; both kernels decide per frame ON THE DEVICE from the coefficients, the host-side counts below only attribute the work.
-    //   default: calls it can run ALONE — PLAIN from 2048 keys, fused OUTER from 1024 (S = 4096: plain 648 -> 588 us, outer 1160 -> 1078;
-    //   S = 1024: outer 163.5 -> 161.1, but plain 93 -> 110: its one workgroup per CU cannot hide the per-workgroup start-up of a
-    //   16-tile stream; profiles/r03_attn_notes.txt).
-    //   ATTN_V2 = 0 never; 1 wherever supported (tests) — calls it cannot run alone (INNER, pure OUTER) are then split: single-segment
-    //   frames here, the others on aid_attn_kernel in a second launch.
+    // d = 64, whole key tiles: the ping-pong kernel (aid_attn_pp.hip).  It runs every kind of frame — one key segment (PLAIN, riders,
+    // fused end points), two (fused INNER, one-sided OUTER), three (fused OUTER) — deciding per frame ON THE DEVICE from the
+    // coefficients like aid_attn_kernel; the host-side counts below only attribute the work.
+    //   default: calls it can run ALONE (several segments per frame: multiples of 512 keys), fused OUTER from 1024 keys, everything
+    //   else from 2048 — same-process A/B, us: S = 4096 plain 648 -> 588, outer 1160 -> 1078, inner 915 -> 860; S = 1024 outer
+    //   163.5 -> 161.1, inner 130.6 -> 135.3, plain 93 -> 110 (a 16-tile stream on one workgroup per CU; profiles/r03_attn_notes.txt).
+    //   ATTN_V2 = 0 never; 1 wherever supported (tests) — a call it cannot run alone is then split: single-segment frames here, the
+    //   others on aid_attn_kernel in a second launch.
     const int n_single = a.mode == AID_MODE_PLAIN ? a.n_frames : a.n_plain + ((a.fused && a.n_frames - a.n_plain >= 2) ? 2 : 0);
-    const bool alone = a.mode == AID_MODE_PLAIN || (a.mode == AID_MODE_OUTER && a.fused && a.l % 512 == 0);     // (segments of whole 8-tile trips)
+    // (a call with several segments per frame: segments of whole 8-tile trips; INNER: k2 / vt2 present)
+    const bool alone = a.mode == AID_MODE_PLAIN || (a.l % 512 == 0 && (a.mode == AID_MODE_OUTER || (a.k2 && a.vt2)));
+    const bool dflt = a.l >= ((a.mode == AID_MODE_OUTER && a.fused) ? 1024 : 2048);
     const int v2 = aid::tune(aid::TUNE_ATTN_V2);
     const bool use_pp = aid::attn_pp_supported(a) && (alone || n_single > 0) &&
-                        (v2 == 1 || (v2 < 0 && alone && a.l >= (a.mode == AID_MODE_PLAIN ? 2048 : 1024)));
+                        (v2 == 1 || (v2 < 0 && alone && dflt));
     if (use_pp) {
         char nm[64];
         snprintf(nm, sizeof(nm), "aid_attn_pp<%s,d64%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16",
-                 a.mode == AID_MODE_PLAIN ? "" : alone ? ",outer" : ",riders");
+                 a.mode == AID_MODE_PLAIN ? "" : !alone ? ",riders" : a.mode == AID_MODE_OUTER ? ",outer" : ",inner");
         const double f1 = alone ? flops : per_seg * n_single;
         ProfScope ps(static_cast<hipStream_t>(stream), nm, f1, alone ? bytes : bytes * n_single / a.n_frames,
                      alone ? flops_exec : f1);
         e = aid::attn_pp_launch(a, static_cast<hipStream_t>(stream), alone);
-        g_variant = alone && a.mode != AID_MODE_PLAIN ? "aid_attn_pp<d64,outer>" : "aid_attn_pp<d64>";
+        g_variant = !alone || a.mode == AID_MODE_PLAIN ? "aid_attn_pp<d64>" : a.mode == AID_MODE_OUTER ? "aid_attn_pp<d64,outer>" : "aid_attn_pp<d64,inner>";
     }
     if (e == hipSuccess && !(use_pp && alone)) {
         const char* nm = aid::attn_variant_name(a);

@@ -1,6 +1,6 @@
-// Ping-pong attention core for head dim 64 and ONE key segment per frame — plain attention (de-activated passes, reference
-// interpolation.py:581-584), the PLAIN rider frames of a batched-CFG call and the fused END-POINT frames of an INNER / OUTER call
-// (their second segment would be their own keys again, see aid_attn.hip).  Same arithmetic as aid_attn_kernel (swapped
+// Ping-pong attention core for head dim 64 and whole 64-key tiles — plain attention (de-activated passes, reference
+// interpolation.py:581-584), the PLAIN riders of a batched-CFG call, and the interpolated frames of INNER / OUTER calls
+// (interpolation.py:626-664, 760-790) as ONE tile stream over the frame's key segments.  Same arithmetic as aid_attn_kernel (swapped
 // products, softmax arithmetic in the matrix pipe, lazy row reference); what differs is WHO does what WHEN:
 //
 //   One workgroup = 8 waves x 32 query rows of one (frame, head); waves w and w + 4 share a SIMD.  Waves 0-3 and waves 4-7
@@ -17,9 +17,9 @@
 //   unpadded 128 B, bank conflicts are avoided by the XOR swizzle of the GEMM (on the DMA source address and on the read).
 //   The main loop is unrolled by eight so the ring stage is a constant: it sits in the offset field of every ds_read.
 //
-// Measured (profiles/r03_attn_notes.txt): S = 4096 plain 588 us against 648 for the program-order kernel; S = 1024 110 against 96
-// (one workgroup per CU: nothing hides the ~7 us start-up of a workgroup that lives 34 intervals).  aid_attn_fwd uses it for
-// single-segment calls from 2048 keys up.
+// Measured (profiles/r03_attn_notes.txt): S = 4096 plain 588 us against 648 for the program-order kernel, fused outer 1078 against
+// 1160, fused inner 860 against 915; S = 1024 plain 110 against 96 (a 16-tile stream on one workgroup per CU).  aid_attn_fwd's
+// default rule: fused OUTER from 1024 keys, everything else from 2048.
 #include <type_traits>
 
 #include "aid_common.hpp"
@@ -78,29 +78,45 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const int h = lid / (p.nqb * a.n_frames);
     const int q0 = (qb * 8 + wave) * 32;
     const int kvf = a.kv_map ? a.kv_map[fr] : fr;
-    // Frames with more than one key segment (interior frames of an INNER / OUTER call) belong to aid_attn_kernel, which is
-    // launched next to this kernel and skips the frames this one runs: BOTH evaluate the same predicate on the device
-    // coefficients, so the split is exact whatever the host-side hints say.
-    // A fused OUTER frame that is not single walks own keys -> begin keys -> end keys (reference interpolation.py:626-664: two
-    // softmaxes over [own ; begin] and [own ; end], outputs mixed (1 - c) : c).  The state after the own segment serves both: it is
-    // PARKED in registers (po / pl / pm) when the begin segment starts and swapped back in when the end segment starts, while the
-    // parked registers take the finished begin side.  c == 0 / c == 1 (not an end-point row): the zero-weighted side is dropped.
-    int nseg = 1, seg1 = 0, seg2 = 0;                           // key / value rows of segments 1 and 2 (segment 0 = kvf)
+    // Key segments of this frame (the same decisions aid_attn_kernel takes, on the same device coefficients):
+    //   single  — PLAIN call, negative coefficient (PLAIN rider of a batched-CFG call), fused END-POINT frame: own keys only.
+    //   OUTER   — reference interpolation.py:626-664: softmaxes over [own ; begin] and [own ; end] (fused) or over begin and end
+    //             (pure), outputs mixed (1 - c) : c.  The walk is own -> begin -> end as ONE tile stream; the state after the own
+    //             segment serves both sides: it is PARKED in registers (po / pl / pm) when the begin segment starts and swapped
+    //             back in when the end segment starts, while the parked registers take the finished begin side (pure: the parked
+    //             state is the empty one).  c == 0 / c == 1: the zero-weighted side is dropped.
+    //   INNER   — interpolation.py:760-790: one softmax over [own ; mix] (fused) or mix (pure); mix = the interpolated keys / values
+    //             aid_lerp_kv wrote to k2 / vt2 (row = frame), or the begin / end row itself for c == 0 / 1.
+    // A launch that does not own the whole call (p.multi == 0: the split launches behind ATTN_V2 = 1) runs single frames only.
+    int nseg = 1, seg0 = kvf, seg1 = 0, seg2 = 0;               // key / value rows of the segments
+    int t2mask = 0;                                             // bit s: segment s reads k2 / vt2
+    int park_at = -1, swap_at = -1;                             // segment index in front of which the state is parked / swapped
     const int row_b = a.begin, row_e = a.end;
     float w_b = 0.f, w_e = 1.f;
-    bool two_sides = false;
     if (a.mode != AID_MODE_PLAIN) {
         const float cf = a.coef[fr];
         const bool single = cf < 0.f || (a.fused && ((cf == 0.f && kvf == row_b) || (cf == 1.f && kvf == row_e)));
         if (!single) {
-            if (!(p.multi && a.mode == AID_MODE_OUTER && a.fused)) return;
+            if (!p.multi) return;
             // (arithmetic, not `c == 1 ? a.end : a.begin`: a select between two FIELDS of the by-value argument struct becomes a
             //  select between their addresses and hipcc then keeps the whole struct in scratch)
-            two_sides = cf != 0.f && cf != 1.f;
-            nseg = two_sides ? 3 : 2;
-            seg1 = row_b + (cf == 1.f ? 1 : 0) * (row_e - row_b);
-            seg2 = row_e;
-            if (two_sides) { w_b = 1.f - cf; w_e = cf; }
+            const bool both = cf != 0.f && cf != 1.f;
+            const int side = row_b + (cf == 1.f ? 1 : 0) * (row_e - row_b);       // the end-point row of a one-sided frame
+            const int fz = a.fused ? 1 : 0;
+            if (a.mode == AID_MODE_OUTER) {
+                nseg = fz + (both ? 2 : 1);
+                const int first = both ? row_b : side;
+                seg0 = fz * kvf + (1 - fz) * first;
+                seg1 = fz * first + (1 - fz) * row_e;
+                seg2 = row_e;
+                if (both) { w_b = 1.f - cf; w_e = cf; park_at = fz ? 1 : -1; swap_at = fz + 1; }
+            } else {
+                nseg = fz + 1;
+                const int mix = both ? fr : side;
+                seg0 = fz * kvf + (1 - fz) * mix;
+                seg1 = mix;
+                t2mask = both ? (fz ? 2 : 1) : 0;
+            }
         }
     }
 
@@ -133,8 +149,13 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const Rsrc rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Vg), 0, 0x7fffffff, 0x00020000);
     const int nt = a.l / PKT;                                   // tiles per segment
     const int NT = nseg * nt;                                   // tiles of this workgroup's stream
-    const int ks0 = kvf * (int)a.k_fs * 2, ks1 = seg1 * (int)a.k_fs * 2, ks2 = seg2 * (int)a.k_fs * 2;
-    const int vs0 = kvf * (int)a.vt_fs * 2, vs1 = seg1 * (int)a.vt_fs * 2, vs2 = seg2 * (int)a.vt_fs * 2;
+    const int ks0 = seg0 * (int)a.k_fs * 2, ks1 = seg1 * (int)a.k_fs * 2, ks2 = seg2 * (int)a.k_fs * 2;
+    const int vs0 = seg0 * (int)a.vt_fs * 2, vs1 = seg1 * (int)a.vt_fs * 2, vs2 = seg2 * (int)a.vt_fs * 2;
+    // INNER: the interpolated keys / values live in their own tensors (same layout, row = frame)
+    const T* K2g = reinterpret_cast<const T*>(a.k2) + h * D;
+    const T* V2g = reinterpret_cast<const T*>(a.vt2) + (int64_t)(h * D) * a.ldvt;
+    const Rsrc rk2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(K2g), 0, 0x7fffffff, 0x00020000);
+    const Rsrc rv2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(V2g), 0, 0x7fffffff, 0x00020000);
     const int prow = 8 * wave + (lane >> 3);                    // tile row this lane fetches
     const int pch = (lane & 7) ^ ((prow >> 1) & 7);             // logical 16-B chunk stored at slot lane & 7 (XOR swizzle)
     const int kvo = prow * (a.ldk * 2) + pch * 16;              // + key0 * ldk * 2 (scalar)
@@ -146,8 +167,13 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         // (arithmetic on values: `sg == 0 ? ks0 : ...` is a select between ADDRESSES of captured variables and keeps them in scratch)
         const int ko = ks0 + (sg >= 1 ? ks1 - ks0 : 0) + (sg >= 2 ? ks2 - ks1 : 0);
         const int vo = vs0 + (sg >= 1 ? vs1 - vs0 : 0) + (sg >= 2 ? vs2 - vs1 : 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)st, 16, kvo, ko + t * PKT * a.ldk * 2, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(st + PNS * PTILE), 16, vvo, vo + t * PKT * 2, 0, 0);
+        if ((t2mask >> sg) & 1) {                               // (a branch, not a select between the two descriptors)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk2, (__attribute__((address_space(3))) void*)st, 16, kvo, ko + t * PKT * a.ldk * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv2, (__attribute__((address_space(3))) void*)(st + PNS * PTILE), 16, vvo, vo + t * PKT * 2, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)st, 16, kvo, ko + t * PKT * a.ldk * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(st + PNS * PTILE), 16, vvo, vo + t * PKT * 2, 0, 0);
+        }
     };
 
     // ---- fragment read offsets: K rows with key bits 2 <-> 3 swapped (so P comes out in B-operand order), V^T rows = channels
@@ -325,6 +351,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[b][r] += back;
+        if (park_at < 0) fresh = true;                          // pure OUTER: the end side starts from the empty state
     };
 
     // fence between a slot's last MFMAs and the VALU code of the next slot that reads their results (20 wait states; the hazard
@@ -370,8 +397,8 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // and fragment read — is a compile-time constant in each copy (segments of a multi-segment frame are multiples of eight tiles).
 #pragma nounroll
     for (int sgi = 0; sgi < nseg; ++sgi) {
-        if (two_sides && sgi == 1) park();
-        if (two_sides && sgi == 2) swap_sides();
+        if (sgi == park_at) park();
+        if (sgi == swap_at) swap_sides();
         const int t_end = min((sgi + 1) * nt, NT - 1);          // V(t) + M(t + 1) for the tiles t of this segment; the stream's last
         for (int t8 = sgi * nt; t8 < t_end; t8 += 8) {          // tile is finished behind the loop
 #pragma unroll

@@ -58,7 +58,7 @@ enum Tune {
     TUNE_ATTN_RES,              // 0 / 1 resident key segments
     TUNE_ATTN_RES_CHUNKS,       // > 0: chunks per (frame, head) of the resident variant
     TUNE_ATTN_ORDER,            // 0 = plain XCD order for mixed launches
-    TUNE_ATTN_V2,               // ping-pong d = 64 kernel: 0 never / 1 wherever supported; default: PLAIN l >= 2048, fused OUTER l >= 1024
+    TUNE_ATTN_V2,               // ping-pong d = 64 kernel: 0 never / 1 wherever supported; default: fused OUTER l >= 1024, everything else l >= 2048
     TUNE_COUNT
 };
 int tune(int id);

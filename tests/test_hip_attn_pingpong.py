@@ -99,6 +99,34 @@ def test_fused_outer_call_runs_alone_on_the_pingpong_kernel(dtype, l, s, riders,
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("mode,fused", [("outer", False), ("inner", True), ("inner", False)])
+def test_inner_and_pure_outer_calls_run_alone_on_the_pingpong_kernel(dtype, mode, fused, tuning):
+    """INNER ([own ; mix] or mix alone, mix = the interpolated keys / values in k2 / vt2 or an end-point row for c = 0 / 1) and pure
+    OUTER (begin side, then the end side from the EMPTY state) with riders and with interior rows whose coefficient is exactly 0 / 1."""
+    tuning("ATTN_V2", 1)
+    n, s, l, h, riders = 7, 150, 512, 2, 3
+    q, k, v, vt = _inputs(n + riders, s, l, h, dtype, seed=len(mode) + 2 * fused)
+    k[0, 100] = q[2, 7] * 5.0                                   # a spike in the begin keys and one in the end keys
+    k[n - 1, 300] = q[3, 11] * 6.0
+    vt = v.transpose(1, 2).contiguous()
+    coef = torch.from_numpy(O.beta_coefs(n, 3, 3)).float()
+    coef[1], coef[5] = 0.0, 1.0
+    cd = torch.cat([coef.to(dtype).float(), -torch.ones(riders)])
+    args = dict(l=l, mode=mode, fused=fused, coef=cd.to(DEV), begin=0, end=n - 1, n_plain=riders)
+    o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, **args)
+    assert ops.last_attn_variant() == f"aid_attn_pp<d64,{mode}>"
+    q64, k64, v64 = to_np64(q), to_np64(k), to_np64(v)
+    ref = np.concatenate([O.attn_core(q64[:n], k64[:n], v64[:n], h, 64 ** -0.5, mode, fused, coef.to(dtype).float().numpy()),
+                          O.attn_core(q64[n:], k64[n:], v64[n:], h, 64 ** -0.5, "plain", False, None)])
+    for f in range(n + riders):
+        assert rel_l2(to_np64(o[f]), ref[f]) < TOL[dtype], f
+    assert torch.isfinite(o).all() and worst(to_np64(o), ref) < WORST[dtype]
+    tuning("ATTN_V2", 0)
+    o_old = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, **args)
+    assert "aid_attn_pp" not in ops.last_attn_variant() and rel_l2(to_np64(o), to_np64(o_old)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
 def test_fused_outer_rescales_inside_the_begin_and_end_segments(dtype, tuning):
     """Spiked keys in the END-POINT frames: the begin side's row reference leaves the parked one behind (the first end tile's scores
     are shifted back by the difference), then the end side raises it again; accumulate + scales on the three-segment path."""
@@ -162,12 +190,13 @@ def test_accumulate_scales_kv_map_and_determinism(tuning):
 
 
 def test_default_rule_for_the_pingpong_kernel(tuning):
-    """No knob: PLAIN calls from 2048 keys and fused OUTER calls from 1024 (multiples of 512) run on the ping-pong kernel; shorter
-    ones, pure OUTER and INNER calls do not."""
+    """No knob: fused OUTER calls from 1024 keys, every other call from 2048 keys run on the ping-pong kernel (calls with several
+    segments per frame: multiples of 512 keys); shorter ones do not."""
     dtype, h = torch.bfloat16, 1
     for l, mode, fused, want in ((2048, "plain", False, True), (1024, "plain", False, False), (2048, "outer", True, True),
-                                 (1024, "outer", True, True), (512, "outer", True, False), (2048, "outer", False, False),
-                                 (2048, "inner", True, False), (2112, "outer", True, False)):
+                                 (1024, "outer", True, True), (512, "outer", True, False), (2048, "outer", False, True),
+                                 (2048, "inner", True, True), (1024, "inner", True, False), (2048, "inner", False, True),
+                                 (2112, "outer", True, False), (2112, "plain", False, True)):
         q, k, v, vt = _inputs(3, 32, l, h, dtype, seed=l)
         coef = torch.tensor([0.0, 0.5, 1.0])
         ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused,

@@ -22,8 +22,8 @@ dev = torch.device("cuda:0")
 lib = aid_amd._lib.load()
 
 SHAPES = {
-    "sdxl": [("sdxl S4096 d64 H10", torch.bfloat16, 4096, 4096, 10, 64, ["outer", "plain"]),
-             ("sdxl S1024 d64 H20", torch.bfloat16, 1024, 1024, 20, 64, ["outer", "plain"]),
+    "sdxl": [("sdxl S4096 d64 H10", torch.bfloat16, 4096, 4096, 10, 64, ["outer", "plain"] + (["inner"] if "--inner" in sys.argv else [])),
+             ("sdxl S1024 d64 H20", torch.bfloat16, 1024, 1024, 20, 64, ["outer", "plain"] + (["inner"] if "--inner" in sys.argv else [])),
              ("sdxl S1024 x77 d64", torch.bfloat16, 1024, 77, 20, 64, ["outer", "plain"]),
              ("sdxl S4096 x77 d64", torch.bfloat16, 4096, 77, 10, 64, ["outer", "plain"])],
     "sd15": [("sd15 S4096 d40 H8", torch.float16, 4096, 4096, 8, 40, ["inner", "plain"]),
