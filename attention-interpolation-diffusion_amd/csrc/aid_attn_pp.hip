@@ -160,19 +160,29 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const int pch = (lane & 7) ^ ((prow >> 1) & 7);             // logical 16-B chunk stored at slot lane & 7 (XOR swizzle)
     const int kvo = prow * (a.ldk * 2) + pch * 16;              // + key0 * ldk * 2 (scalar)
     const int vvo = prow * (a.ldvt * 2) + pch * 16;             // + key0 * 2       (scalar)
-    auto dma_tile = [&](int g) __attribute__((always_inline)) {     // g: tile of the stream = segment g / nt, tile g % nt of it
-        char* st = smem + (g & (PNS - 1)) * PTILE + wave * 1024;         // g & 7 is a constant wherever the caller's is (main loop)
-        const int sg = (g >= nt) + (g >= 2 * nt);
-        const int t = g - sg * nt;
-        // (arithmetic on values: `sg == 0 ? ks0 : ...` is a select between ADDRESSES of captured variables and keeps them in scratch)
-        const int ko = ks0 + (sg >= 1 ? ks1 - ks0 : 0) + (sg >= 2 ? ks2 - ks1 : 0);
-        const int vo = vs0 + (sg >= 1 ? vs1 - vs0 : 0) + (sg >= 2 ? vs2 - vs1 : 0);
-        if ((t2mask >> sg) & 1) {                               // (a branch, not a select between the two descriptors)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk2, (__attribute__((address_space(3))) void*)st, 16, kvo, ko + t * PKT * a.ldk * 2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv2, (__attribute__((address_space(3))) void*)(st + PNS * PTILE), 16, vvo, vo + t * PKT * 2, 0, 0);
+    // The DMA stream walks the frame's segments tile by tile with RUNNING scalar offsets (two s_add per tile; the per-tile
+    // segment / tensor arithmetic of a random-access `tile g` cost ~45 SALU instructions in every V slot and 4 % of the kernel):
+    // dk / dv = byte offsets of the next tile to request, dleft = tiles left in its segment, dseg = that segment, d2 = it reads k2 / vt2
+    int dk = ks0, dv = vs0, dleft = nt, dseg = 0;
+    bool d2 = (t2mask & 1) != 0;
+    const int kstep = PKT * a.ldk * 2;
+    auto dma_next = [&](int st) __attribute__((always_inline)) {    // st: ring stage, a constant wherever the caller's tile index is
+        char* dst = smem + st * PTILE + wave * 1024;
+        if (d2) {                                               // (a branch, not a select between the two descriptors)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk2, (__attribute__((address_space(3))) void*)dst, 16, kvo, dk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv2, (__attribute__((address_space(3))) void*)(dst + PNS * PTILE), 16, vvo, dv, 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)st, 16, kvo, ko + t * PKT * a.ldk * 2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(st + PNS * PTILE), 16, vvo, vo + t * PKT * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)dst, 16, kvo, dk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dst + PNS * PTILE), 16, vvo, dv, 0, 0);
+        }
+        dk += kstep;
+        dv += PKT * 2;
+        if (--dleft == 0) {                                     // next segment (arithmetic on values, see above)
+            ++dseg;
+            dk = ks1 + (dseg >= 2 ? ks2 - ks1 : 0);
+            dv = vs1 + (dseg >= 2 ? vs2 - vs1 : 0);
+            d2 = ((t2mask >> dseg) & 1) != 0;
+            dleft = nt;
         }
     };
 
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         const bool issue = t + LEAD < NT;
 #ifdef AID_ABLATIONS
         if (p.abl & 1) {                                        // 1: no VALU work in the V slot
-            if (!(p.abl & 2) && issue) dma_tile(t + LEAD);
+            if (!(p.abl & 2) && issue) dma_next((t + LEAD) & (PNS - 1));
             fresh = false;
             retire(NT - 4 - t);
             return;
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 #ifdef AID_ABLATIONS
             && !(p.abl & 2)
 #endif
-        ) dma_tile(t + LEAD);
+        ) dma_next((t + LEAD) & (PNS - 1));
         float xm = fmaxf(sc[0][0], sc[0][1]);
 #ifdef AID_ABLATIONS
         if (!(p.abl & 8))                                       // 8: no head-room check (the maximum chain)
@@ -320,7 +330,8 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
                 pf[2 * b + u] = cvt8<T>(pv);
             }
-        retire(NT - 4 - t);
+        if (issue) wait_vm<6>();                                // steady state: the three tiles behind t + 3 stay in flight
+        else       retire(NT - 4 - t);
     };
 
     // Segment boundaries of a two-sided frame.  S(t) of the next segment's first tile is in `sc` and PV(t - 1) closed the segment
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // ---- prologue: pieces of tiles 0 .. 5 requested, 0 .. 2 retired and published; S(0); fragments of K(1) ----------------
 #pragma unroll
     for (int t = 0; t < LEAD; ++t)
-        if (t < NT) dma_tile(t);
+        if (t < NT) dma_next(t);
     retire(NT - 3);
     slot_barrier();
     if (grp == 1) slot_barrier();                               // the second group runs one barrier behind
