@@ -204,10 +204,12 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     bool fresh = true;
     f32x16 o[2], ol, sc[2];
     T8 pf[4];
+    f32x16 cneg;                        // -m as an accumulator block (C operand of a tile's first score MFMAs), rebuilt when m moves
     f32x16 po[2];                       // parked: O of the own-keys state while the begin side runs, then the finished begin side
     float pl = 0.f, pm = 0.f;           // parked row sum (this lane's register of the row-sum block) and row reference
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; po[0][r] = 0.f; po[1][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; po[0][r] = 0.f; po[1][r] = 0.f; cneg[r] = 0.f; }
+    asm volatile("" : "+v"(cneg));
 #pragma unroll
     for (int i = 0; i < 4; ++i) pf[i] = zero8<T>();
 
@@ -250,9 +252,6 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             return;
         }
 #endif
-        f32x16 cneg;                                            // -m as an accumulator block: C operand of the first score MFMAs
-#pragma unroll                                                  // (kept across slots it measured the same and costs 16 registers)
-        for (int r = 0; r < 16; ++r) cneg[r] = -m;
         pin();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -313,6 +312,9 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             const float alpha = __builtin_amdgcn_exp2f(-shift);
             m += shift;
 #pragma unroll
+            for (int r = 0; r < 16; ++r) cneg[r] = -m;
+            asm volatile("" : "+v"(cneg));                      // (opaque: keeps hipcc from rebuilding the block in every M slot)
+#pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; ol[r] *= alpha; }
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -358,6 +360,9 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         ol[0] = pl;                                             // (the other registers of the row-sum block are zero in every state)
         const float back = m - pm;                              // S(t) was formed against the begin side's reference (>= the parked one)
         m = pm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cneg[r] = -m;
+        asm volatile("" : "+v"(cneg));
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
