@@ -186,6 +186,67 @@ def test_interpolate_single_end_to_end_vs_oracle_loop(model, dtype, atype):
     assert out.shape == (3, 4, 8, 8) and err < PIPE_BOUND[dtype], err
 
 
+def _slerp64(a, b, t):
+    """interpolation.py:861-918 restated on numpy fp64: row-wise over the last dim, lerp fallback at |cos| > 0.9995."""
+    a2, b2 = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+    out = np.empty_like(a2)
+    for r in range(a2.shape[0]):
+        u, v = a2[r], b2[r]
+        cos = float(np.dot(u, v) / (np.linalg.norm(u) * np.linalg.norm(v)))
+        if abs(cos) > 0.9995:
+            out[r] = (1 - t) * u + t * v
+        else:
+            th = np.arccos(cos)
+            out[r] = (np.sin((1 - t) * th) * u + np.sin(t * th) * v) / np.sin(th)
+    return out.reshape(a.shape)
+
+
+def test_interpolate_single_against_an_independently_written_loop():
+    """The orchestration of interpolate_single — batch [start, target(it), end], latents slerp'd / embeddings lerp'd at `it`, AID active
+    on the text pass of steps i < int(T * warmup_ratio) with coefficients [0, it, 1], de-activated for the unconditional pass and
+    afterwards, classifier-free guidance, DDIM update — written out AGAIN here from reference pipeline_interpolated_sd.py:1690-1747 and
+    :1831-1907 (numpy fp64, oracle attention, no pipelines.py / sequence.py / interp.py), against the HIP pipeline."""
+    dtype, steps, it, gs, ratio = torch.float16, 6, 0.35, 5.0, 0.5
+    hip = StackDenoiser("sd15", dtype=dtype, device=DEV, scale_down=16, latent_hw=(8, 8))
+    g = torch.Generator().manual_seed(12)
+    l0, l1 = torch.randn(1, 4, 8, 8, generator=g).to(dtype), torch.randn(1, 4, 8, 8, generator=g).to(dtype)
+    rd = lambda t: tuple(e.to(dtype).float() for e in t)     # noqa: E731
+    es, ee = rd(_embs(g, 768)), rd(_embs(g, 768))             # (positive, negative) embeddings of the two prompts
+    pipe = InterpolationStableDiffusionPipeline(hip, DDIMSchedulerLite())
+    pipe.load_aid(t=0.5, is_fused=True, atype="fused_inner")
+    out = pipe.interpolate_single(it, latent_start=l0, latent_end=l1, embeds_start=es, embeds_end=ee, num_inference_steps=steps,
+                                  warmup_ratio=ratio, guidance_scale=gs, output_type="latent")["images"]
+
+    # ---- the same run, written out again ----
+    den = OracleDenoiser(hip)
+    procs = list(hip.attn_processors.values())
+    a64 = lambda t: t.double().numpy()                          # noqa: E731
+    lat = np.concatenate([a64(l0), _slerp64(a64(l0), a64(l1), it), a64(l1)])                 # :1690-1706
+    cond = np.concatenate([a64(es[0]), (1 - it) * a64(es[0]) + it * a64(ee[0]), a64(ee[0])])   # :1716-1730 ("linear" init)
+    unc = np.concatenate([a64(es[1]), (1 - it) * a64(es[1]) + it * a64(ee[1]), a64(ee[1])])
+    # SD's scheduler configuration: scaled-linear betas 0.00085 .. 0.012 over 1000 steps, "leading" spacing, steps_offset 1
+    ac = np.cumprod(1.0 - np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2)
+    ts = [int(v) for v in (np.arange(steps) * (1000 // steps))[::-1] + 1]
+    warm = int(steps * ratio)                                                               # :1831
+    for i, t in enumerate(ts):
+        for p_ in procs:                                                                    # :1845-1848
+            if i < warm:
+                p_.activate(it)
+            else:
+                p_.deactivate()
+        eps_text = den(torch.from_numpy(lat), t, torch.from_numpy(cond))[0].numpy()
+        for p_ in procs:                                                                    # :1870
+            p_.deactivate()
+        eps_unc = den(torch.from_numpy(lat), t, torch.from_numpy(unc))[0].numpy()
+        eps = eps_unc + gs * (eps_text - eps_unc)                                           # :1892
+        a_t = ac[t]                                                                         # DDIM, eta = 0 (Song et al. 2021, eq. 12)
+        a_prev = ac[ts[i + 1]] if i + 1 < len(ts) else 1.0
+        x0 = (lat - np.sqrt(1 - a_t) * eps) / np.sqrt(a_t)
+        lat = np.sqrt(a_prev) * x0 + np.sqrt(1 - a_prev) * eps
+    err = rel_l2(to_np64(out), lat)
+    assert out.shape == (3, 4, 8, 8) and err < PIPE_BOUND[dtype], err
+
+
 @pytest.mark.parametrize("guided", [False, True])
 def test_n_frame_interpolate_end_to_end_vs_oracle_loop(guided):
     dtype, steps, size = torch.float16, 4, 5
