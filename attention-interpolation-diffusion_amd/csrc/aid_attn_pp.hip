@@ -62,6 +62,10 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     constexpr float XTH = std::is_same<T, f16>::value ? 15.0f : 60.0f;      // head-room (log2) of P = 2^x in the storage type
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef AID_ABLATIONS
+    long long tl[6];                                            // 32: workgroup timeline (shader cycles), written over the output rows
+    tl[0] = clock64();
+#endif
     const AidAttnArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -389,7 +393,13 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 #pragma unroll
     for (int t = 0; t < LEAD; ++t)
         if (t < NT) dma_next(t);
+#ifdef AID_ABLATIONS
+    if (p.abl & 32) { tl[1] = clock64(); asm volatile("" :: "v"(qf[0]), "v"(qf[3])); }
+#endif
     retire(NT - 3);
+#ifdef AID_ABLATIONS
+    if (p.abl & 32) tl[2] = clock64();
+#endif
     slot_barrier();
     if (grp == 1) slot_barrier();                               // the second group runs one barrier behind
 #pragma unroll
@@ -409,6 +419,9 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     }
     settle();
     slot_barrier();
+#ifdef AID_ABLATIONS
+    if (p.abl & 32) tl[3] = clock64();
+#endif
     // One pass per key segment (`nounroll`: one copy of the body); inside, eight tiles per trip: t & 7 — the ring stage of every DMA
     // and fragment read — is a compile-time constant in each copy (segments of a multi-segment frame are multiples of eight tiles).
 #pragma nounroll
@@ -452,6 +465,15 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 
     // ---- finish: O / l, lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3} ----------------------
 #ifdef AID_ABLATIONS
+    if (p.abl & 32) {
+        tl[4] = clock64();
+        if (lane == 0 && q0 < a.s) {
+            float* dbg = reinterpret_cast<float*>(reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q0 * a.ldo + h * D);
+            for (int i = 1; i < 5; ++i) dbg[i - 1] = (float)(tl[i] - tl[0]);
+            dbg[4] = (float)(tl[0] & 0xffffff);
+        }
+        return;
+    }
     if (p.abl & 16) {
         if (lane == 0 && q0 < a.s) {
             float* dbg = reinterpret_cast<float*>(reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q0 * a.ldo + h * D);
