@@ -44,6 +44,24 @@ struct AttnPPParams {
 
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 
+// acc + lo(w) + hi(w) for a register holding two storage-type values (v_dot2c_f32_bf16 / v_dot2c_f32_f16 against (1, 1))
+template <typename T>
+__device__ __forceinline__ float dot2_ones(uint32_t w, float acc);
+template <>
+__device__ __forceinline__ float dot2_ones<bf16>(uint32_t w, float acc) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 one;
+    one[0] = (__bf16)1.0f; one[1] = (__bf16)1.0f;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w), one, acc, false);
+}
+template <>
+__device__ __forceinline__ float dot2_ones<f16>(uint32_t w, float acc) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 one;
+    one[0] = (_Float16)1.0f; one[1] = (_Float16)1.0f;
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), one, acc, false);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -140,9 +158,6 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             }
         }
     }
-    T8 onesf;                                                   // A fragment of the row-sum block: row 0 = ones
-#pragma unroll
-    for (int e = 0; e < 8; ++e) onesf[e] = (l31 == 0) ? (T)1.0f : (T)0.0f;
 
     // ---- DMA addressing: this wave's piece (8 rows x 128 B) of every K tile and of every V^T tile ------------
     // one descriptor per tensor (this head's columns / rows); the key / value ROW of a segment goes into the scalar offset
@@ -206,13 +221,14 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // ---- online-softmax state -----------------------------------------------------------------------
     float m = 0.f;
     bool fresh = true;
-    f32x16 o[2], ol, sc[2];
+    f32x16 o[2], sc[2];
+    float lsum = 0.f;                   // row sum of the ROUNDED P over the 32 keys per tile this lane holds (the partner lane has the others)
     T8 pf[4];
     f32x16 cneg;                        // -m as an accumulator block (C operand of a tile's first score MFMAs), rebuilt when m moves
     f32x16 po[2];                       // parked: O of the own-keys state while the begin side runs, then the finished begin side
     float pl = 0.f, pm = 0.f;           // parked row sum (this lane's register of the row-sum block) and row reference
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; ol[r] = 0.f; po[0][r] = 0.f; po[1][r] = 0.f; cneg[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; po[0][r] = 0.f; po[1][r] = 0.f; cneg[r] = 0.f; }
     asm volatile("" : "+v"(cneg));
 #pragma unroll
     for (int i = 0; i < 4; ++i) pf[i] = zero8<T>();
@@ -266,15 +282,12 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             pin();
         }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int kk = i / 3, w = i % 3;
-            if (w < 2) o[w] = mfma32(vf[kk][w], pf[kk], o[w]);
-            else       ol = mfma32(onesf, pf[kk], ol);
+        for (int i = 0; i < 8; ++i) {
+            const int kk = i >> 1, w = i & 1;
+            o[w] = mfma32(vf[kk][w], pf[kk], o[w]);
             pin();
-            if (i >= 2 && i < 10) {
-                kf[(i - 2) >> 1][(i - 2) & 1] = lds_k(sk, (i - 2) >> 1, (i - 2) & 1);
-                pin();
-            }
+            kf[kk][w] = lds_k(sk, kk, w);                       // (kf[kk][w] was released by score MFMA 2 kk + w, eight or more MFMAs ago)
+            pin();
         }
     };
 
@@ -319,7 +332,8 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             for (int r = 0; r < 16; ++r) cneg[r] = -m;
             asm volatile("" : "+v"(cneg));                      // (opaque: keeps hipcc from rebuilding the block in every M slot)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; ol[r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            lsum *= alpha;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -336,6 +350,13 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
                 pf[2 * b + u] = cvt8<T>(pv);
             }
+        // row sums of the rounded P: v_dot2c against (1, 1), two keys per instruction (the matrix pipe's ones-row block cost 4 of 20 MFMAs)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 w4 = __builtin_bit_cast(u32x4, pf[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lsum = dot2_ones<T>(w4[e], lsum);
+        }
         if (issue) wait_vm<6>();                                // steady state: the three tiles behind t + 3 stay in flight
         else       retire(NT - 4 - t);
     };
@@ -345,13 +366,11 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     auto park = [&]() __attribute__((always_inline)) {          // own keys done: park the state, the begin side continues on it
 #pragma unroll
         for (int r = 0; r < 16; ++r) { po[0][r] = o[0][r]; po[1][r] = o[1][r]; }
-        pl = ol[0];
+        pl = lsum;
         pm = m;
     };
     auto swap_sides = [&]() __attribute__((always_inline)) {    // begin side done: keep (1 - c) O_b / l_b, resume the own-keys state
-        const float lv = ol[0];
-        const float partner = other_half(lv);                   // (all lanes take part in the exchange: not inside the `?:`)
-        const float lrow = hi ? partner : lv;                   // the row sum sits at the lanes of half 0
+        const float lrow = lsum + other_half(lsum);             // (all lanes take part in the exchange)
         const float wb = w_b / lrow;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -361,7 +380,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 o[d][r] = po[d][r];
                 po[d][r] = rb;
             }
-        ol[0] = pl;                                             // (the other registers of the row-sum block are zero in every state)
+        lsum = pl;
         const float back = m - pm;                              // S(t) was formed against the begin side's reference (>= the parked one)
         m = pm;
 #pragma unroll
@@ -378,10 +397,10 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // recogniser does not see across the barrier's asm / branches — aid_attn.hip has the history)
     auto settle = [&]() __attribute__((always_inline)) {
         asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
-        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(ol));
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]));
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
         asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
-        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(ol));
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]));
     };
 
     // Schedule.  Group g runs M(t) in interval 2 t + g and V(t) in 2 t + 1 + g (M(t) computes S(t) and the PV product of tile t - 1).
@@ -456,7 +475,6 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int d = 0; d < 2; ++d) o[d] = mfma32(vf[kk][d], pf[kk], o[d]);
-            ol = mfma32(onesf, pf[kk], ol);
         }
     }
     settle();
@@ -482,9 +500,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         return;
     }
 #endif
-    const float lv = ol[0];
-    const float partner = other_half(lv);                       // the row sum sits at the lanes of half 0
-    const float inv = w_e / (hi ? partner : lv);                // (w_e = 1 unless this frame mixes two sides)
+    const float inv = w_e / (lsum + other_half(lsum));          // (w_e = 1 unless this frame mixes two sides)
     const int q = q0 + l31;
     if (q < a.s) {
         const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
