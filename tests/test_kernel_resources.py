@@ -81,7 +81,7 @@ def test_attention_variants_keep_the_waves_per_simd_the_launcher_assumes():
 
 def test_pingpong_attention_keeps_two_waves_per_simd():
     """The ping-pong kernel's premise is one wave of each group per SIMD (8 waves per CU): <= 256 registers per wave with the parked
-    state of a two-sided frame and the -m block in them (248 at this commit; the park / swap code inside the unrolled tile loop had it at 256 + 14
+    state of a two-sided frame and the -m block in them (232 at this commit; the park / swap code inside the unrolled tile loop had it at 256 + 14
     spills, and a select between two by-value argument fields had put 416 B per lane into scratch)."""
     for sym, r in _table("aid_attn_pp").items():
         if "aid_attn_pp_kernel" in sym:
