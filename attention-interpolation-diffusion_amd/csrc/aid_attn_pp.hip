@@ -1,25 +1,28 @@
 // Ping-pong attention core for head dim 64 and whole 64-key tiles — plain attention (de-activated passes, reference
 // interpolation.py:581-584), the PLAIN riders of a batched-CFG call, and the interpolated frames of INNER / OUTER calls
 // (interpolation.py:626-664, 760-790) as ONE tile stream over the frame's key segments.  Same arithmetic as aid_attn_kernel (swapped
-// products, softmax arithmetic in the matrix pipe, lazy row reference); what differs is WHO does what WHEN:
+// products, -m folded into the score MFMAs' accumulator, lazy row reference; the row sums here are VALU dot products of the rounded P,
+// not a ones-row block); what differs is WHO does what WHEN:
 //
 //   One workgroup = 8 waves x 32 query rows of one (frame, head); waves w and w + 4 share a SIMD.  Waves 0-3 and waves 4-7
 //   run the same program ONE BARRIER APART, and the program alternates two slots per 64-key tile:
-//     M(t)   every MFMA of the tile in one burst: S(t) = K(t) Q'^T - m (8), then O^T += V^T(t-1) P(t-1)^T (12); in their shadow,
+//     M(t)   every MFMA of the tile in one burst: S(t) = K(t) Q'^T - m (8), then O^T += V^T(t-1) P(t-1)^T (8); in their shadow,
 //            one per MFMA and in pinned program order, the 16 operand-fragment reads: V^T(t-1) beside the score MFMAs, K(t+1)
 //            beside the PV MFMAs into the registers the score MFMAs released.  No VALU instruction.
-//     V(t)   the VALU half: head-room check, P(t) = 2^S(t), rounding to the storage type; plus this wave's two LDS-DMA
-//            pieces of tile t + 6 and the counted wait that retires its pieces of tile t + 3
+//     V(t)   the VALU half: head-room check, P(t) = 2^S(t), rounding to the storage type, row sums (v_dot2c); plus this wave's two
+//            LDS-DMA pieces of tile t + 6 and the counted wait that retires its pieces of tile t + 3
 //   so while one wave of a SIMD keeps the matrix pipe busy its partner does the exponentials, and vice versa.  In the
 //   program-order kernel the three co-resident waves of a SIMD drift into the same phase and MFMA time and VALU time add up
 //   (1100 cycles per wave-tile for 640 of MFMA, profiles/r02_attn_notes.txt); here they are complementary by construction.
+//   A frame with several key segments (fused INNER: own + mix; OUTER: own / begin / end with the own-keys state parked in registers
+//   and swapped back) is one stream; the DMA addresses walk it on running scalar offsets.
 //   K / V^T tiles go HBM -> LDS by DMA (no staging registers, no ds_write pass) into a ring of eight 16 KB stages; rows are
 //   unpadded 128 B, bank conflicts are avoided by the XOR swizzle of the GEMM (on the DMA source address and on the read).
 //   The main loop is unrolled by eight so the ring stage is a constant: it sits in the offset field of every ds_read.
 //
-// Measured (profiles/r03_attn_notes.txt): S = 4096 plain 588 us against 648 for the program-order kernel, fused outer 1078 against
-// 1160, fused inner 860 against 915; S = 1024 plain 110 against 96 (a 16-tile stream on one workgroup per CU).  aid_attn_fwd's
-// default rule: fused OUTER from 1024 keys, everything else from 2048.
+// Measured (profiles/r03_attn_notes.txt, same process): S = 4096 plain 597 us against 658 for the program-order kernel, fused outer
+// 1089 against 1213, fused inner 838 against 943; S = 1024 plain 107 against 95 (a 16-tile stream on one workgroup per CU).
+// aid_attn_fwd's default rule: fused OUTER from 1024 keys, everything else from 2048.
 #include <type_traits>
 
 #include "aid_common.hpp"
