@@ -18,7 +18,10 @@ cd $GRAFT_REPO_ROOT
 for w in sdxl sd15; do python tools/stack_breakdown.py $w > $R/breakdown_$w.txt 2>/dev/null; done
 python tools/kbench_proj.py > $R/kbench_proj.txt 2>/dev/null
 python tools/gemm_ab.py "GEMM_TRI=0,GEMM_PP=0" "GEMM_TRI=0,GEMM_PP=1" "GEMM_TRI=-1,GEMM_PP=1" --rounds 5 --iters 10 --torch > $R/gemm_ab.txt 2>/dev/null
-./tools/ubench/mfma_cadence > $R/ubench_mfma_cadence.txt 2>&1; ./tools/ubench/store_bw > $R/ubench_store_bw.txt 2>&1
+for u in mfma_cadence store_bw valu_rate; do
+  [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip
+  ./tools/ubench/$u > $R/ubench_$u.txt 2>&1
+done
 ( for wl in sdxl sd15; do for mode in "off 1" "fused 0" "fused 1"; do set -- $mode
     AID_LN_FOLD=$2 python bench.py --workload $wl --sublayers $1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-also 2>/dev/null | tail -1 |
       python -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], 'sublayers=' + sys.argv[2], 'AID_LN_FOLD=' + sys.argv[3], 'frames/s', round(d['value'], 3), 'ms/step', round(d['ms_per_step'], 3))" $wl $1 $2
