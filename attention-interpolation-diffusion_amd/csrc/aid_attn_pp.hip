@@ -527,7 +527,10 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 // May the ping-pong kernel run the single-segment frames of this call?  d = 64, whole 64-key tiles, at least two of them.
 bool attn_pp_supported(const AidAttnArgs& a) {
     const int64_t kb = (int64_t)a.n_kv * a.k_fs * 2, vb = (int64_t)a.n_kv * a.vt_fs * 2;    // segment rows ride in 32-bit scalar offsets
-    return a.d == 64 && a.l % PKT == 0 && a.l >= 2 * PKT && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && kb < (1ll << 31) && vb < (1ll << 31);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.k2) |
+                         reinterpret_cast<uintptr_t>(a.vt2);                               // LDS-DMA moves 16-byte pieces
+    return a.d == 64 && a.l % PKT == 0 && a.l >= 2 * PKT && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.k_fs % 8 == 0 && a.vt_fs % 8 == 0 &&
+           (al & 15) == 0 && kb < (1ll << 31) && vb < (1ll << 31);
 }
 
 hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) {
