@@ -359,15 +359,15 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     // d = 64, whole key tiles: the ping-pong kernel (aid_attn_pp.hip).  It runs every kind of frame — one key segment (PLAIN, riders,
     // fused end points), two (fused INNER, one-sided OUTER), three (fused OUTER) — deciding per frame ON THE DEVICE from the
     // coefficients like aid_attn_kernel; the host-side counts below only attribute the work.
-    //   default: calls it can run ALONE (several segments per frame: multiples of 512 keys), fused OUTER from 1024 keys, everything
-    //   else from 2048 — same-process A/B, us: S = 4096 plain 648 -> 588, outer 1160 -> 1078, inner 915 -> 860; S = 1024 outer
+    //   default: calls it can run ALONE (several segments per frame: multiples of 512 keys), fused OUTER and INNER from 1024 keys, PLAIN
+    //   and pure OUTER from 2048 — same-process A/B, us: S = 4096 plain 648 -> 588, outer 1160 -> 1078, inner 915 -> 860; S = 1024 outer
     //   163.5 -> 161.1, inner 130.6 -> 135.3, plain 93 -> 110 (a 16-tile stream on one workgroup per CU; profiles/r03_attn_notes.txt).
     //   ATTN_V2 = 0 never; 1 wherever supported (tests) — a call it cannot run alone is then split: single-segment frames here, the
     //   others on aid_attn_kernel in a second launch.
     const int n_single = a.mode == AID_MODE_PLAIN ? a.n_frames : a.n_plain + ((a.fused && a.n_frames - a.n_plain >= 2) ? 2 : 0);
     // (a call with several segments per frame: segments of whole 8-tile trips; INNER: k2 / vt2 present)
     const bool alone = a.mode == AID_MODE_PLAIN || (a.l % 512 == 0 && (a.mode == AID_MODE_OUTER || (a.k2 && a.vt2)));
-    const bool dflt = a.l >= ((a.mode == AID_MODE_OUTER && a.fused) ? 1024 : 2048);
+    const bool dflt = a.l >= ((a.mode == AID_MODE_PLAIN || (a.mode == AID_MODE_OUTER && !a.fused)) ? 2048 : 1024);
     const int v2 = aid::tune(aid::TUNE_ATTN_V2);
     const bool use_pp = aid::attn_pp_supported(a) && (alone || n_single > 0) &&
                         (v2 == 1 || (v2 < 0 && alone && dflt));

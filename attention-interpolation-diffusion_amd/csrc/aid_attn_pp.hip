@@ -40,7 +40,8 @@ constexpr int PNS = 8;                  // ring depth (128 KB)
 struct AttnPPParams {
     AidAttnArgs a;
     int32_t nqb;                        // 256-row q blocks per (frame, head)
-    int32_t multi;                      // 1: this launch also runs the three-segment frames of a fused OUTER call (it is the only launch)
+    int32_t multi;                      // 1: this launch runs every frame of the call (it is the only launch)
+    int32_t persist;                    // 1: one workgroup per CU walks several items (every item is whole 8-tile trips)
     float   c2;                         // softmax_scale * log2(e)
     int32_t abl;                        // development builds (-DAID_ABLATIONS): timing ablations, results are garbage
 };
@@ -93,17 +94,24 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const int grp = wave >> 2;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // [head][frame][q block]: a (frame, head)'s blocks share an L2; three-segment frames first inside every XCD's range
+    // ---- work items: 256 query rows of one (frame, head); order [head][frame][q block] so a (frame, head)'s blocks share an L2, the
+    // three-segment frames first inside every XCD's range.  p.persist == 0: one item per workgroup (hardware dispatch order).
+    // p.persist == 1 (every item is whole 8-tile trips): one workgroup per CU; workgroup b sits on XCD b % 8 and walks ITS XCD's range
+    // in SNAKE order — positions w, 2 W - 1 - w, 2 W + w, ... (w = b / 8, W = workgroups per XCD) — which balances the 3 : 1 mix of heavy
+    // and light items statically (plain round-robin left the first workgroups with all the extra heavy items: -14 %).  The tile stream,
+    // the DMA ring and the slot alternation run on across an item boundary, so a workgroup's ~5 us start-up (dispatch, scalar loads, Q
+    // and six tiles in flight, first product; tools/dev/pp_timeline.py) is paid once per launch instead of once per item.
+    const int nt = a.l / PKT;                                   // tiles per key segment
+    const int n_items = p.nqb * a.n_frames * a.heads;
     const int n_heavy = a.n_frames - a.n_plain;
-    const int lid = (p.multi && a.n_plain > 0 && n_heavy > 0)
-                        ? heavy_first(blockIdx.x, gridDim.x, n_heavy * p.nqb, a.n_frames * p.nqb)
-                        : xcd_remap(blockIdx.x, gridDim.x);
-    const int qb = lid % p.nqb;
-    const int fr = (lid / p.nqb) % a.n_frames;
-    const int h = lid / (p.nqb * a.n_frames);
-    const int q0 = (qb * 8 + wave) * 32;
-    const int kvf = a.kv_map ? a.kv_map[fr] : fr;
-    // Key segments of this frame (the same decisions aid_attn_kernel takes, on the same device coefficients):
+    const bool hf = p.multi && a.n_plain > 0 && n_heavy > 0;
+    const int xcd = blockIdx.x & 7, wx = blockIdx.x >> 3, WX = gridDim.x >> 3;
+    auto vblock = [&](int j) __attribute__((always_inline)) {   // virtual block id of this workgroup's j-th item (>= n_items: none)
+        if (!p.persist) return j == 0 ? (int)blockIdx.x : n_items;
+        const int pos = j * WX + ((j & 1) ? WX - 1 - wx : wx);
+        return xcd + 8 * pos;
+    };
+    // Key segments of a frame (the same decisions aid_attn_kernel takes, on the same device coefficients):
     //   single  — PLAIN call, negative coefficient (PLAIN rider of a batched-CFG call), fused END-POINT frame: own keys only.
     //   OUTER   — reference interpolation.py:626-664: softmaxes over [own ; begin] and [own ; end] (fused) or over begin and end
     //             (pure), outputs mixed (1 - c) : c.  The walk is own -> begin -> end as ONE tile stream; the state after the own
@@ -113,71 +121,101 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     //   INNER   — interpolation.py:760-790: one softmax over [own ; mix] (fused) or mix (pure); mix = the interpolated keys / values
     //             aid_lerp_kv wrote to k2 / vt2 (row = frame), or the begin / end row itself for c == 0 / 1.
     // A launch that does not own the whole call (p.multi == 0: the split launches behind ATTN_V2 = 1) runs single frames only.
-    int nseg = 1, seg0 = kvf, seg1 = 0, seg2 = 0;               // key / value rows of the segments
-    int t2mask = 0;                                             // bit s: segment s reads k2 / vt2
-    int park_at = -1, swap_at = -1;                             // segment index in front of which the state is parked / swapped
     const int row_b = a.begin, row_e = a.end;
-    float w_b = 0.f, w_e = 1.f;
-    if (a.mode != AID_MODE_PLAIN) {
-        const float cf = a.coef[fr];
-        const bool single = cf < 0.f || (a.fused && ((cf == 0.f && kvf == row_b) || (cf == 1.f && kvf == row_e)));
-        if (!single) {
-            if (!p.multi) return;
-            // (arithmetic, not `c == 1 ? a.end : a.begin`: a select between two FIELDS of the by-value argument struct becomes a
-            //  select between their addresses and hipcc then keeps the whole struct in scratch)
-            const bool both = cf != 0.f && cf != 1.f;
-            const int side = row_b + (cf == 1.f ? 1 : 0) * (row_e - row_b);       // the end-point row of a one-sided frame
-            const int fz = a.fused ? 1 : 0;
-            if (a.mode == AID_MODE_OUTER) {
-                nseg = fz + (both ? 2 : 1);
-                const int first = both ? row_b : side;
-                seg0 = fz * kvf + (1 - fz) * first;
-                seg1 = fz * first + (1 - fz) * row_e;
-                seg2 = row_e;
-                if (both) { w_b = 1.f - cf; w_e = cf; park_at = fz ? 1 : -1; swap_at = fz + 1; }
-            } else {
-                nseg = fz + 1;
-                const int mix = both ? fr : side;
-                seg0 = fz * kvf + (1 - fz) * mix;
-                seg1 = mix;
-                t2mask = both ? (fz ? 2 : 1) : 0;
+    // the item being planned (N_*) and the item being computed (no prefix); adopt() moves the one into the other
+    int N_fr = 0, N_h = 0, N_q0 = 0, N_nseg = 1, N_ks0 = 0, N_ks1 = 0, N_ks2 = 0, N_vs0 = 0, N_vs1 = 0, N_vs2 = 0, N_t2 = 0;
+    int N_park = -1, N_swap = -1;
+    float N_wb = 0.f, N_we = 1.f;
+    bool N_skip = false;
+    auto plan = [&](int vb) __attribute__((always_inline)) {
+        const int lid = hf ? heavy_first(vb, n_items, n_heavy * p.nqb, a.n_frames * p.nqb) : xcd_remap(vb, n_items);
+        const int qb = lid % p.nqb;
+        N_fr = (lid / p.nqb) % a.n_frames;
+        N_h = lid / (p.nqb * a.n_frames);
+        N_q0 = (qb * 8 + wave) * 32;
+        const int kvf = a.kv_map ? a.kv_map[N_fr] : N_fr;
+        int seg0 = kvf, seg1 = 0;
+        N_nseg = 1; N_t2 = 0; N_park = -1; N_swap = -1; N_wb = 0.f; N_we = 1.f; N_skip = false;
+        if (a.mode != AID_MODE_PLAIN) {
+            const float cf = a.coef[N_fr];
+            const bool single = cf < 0.f || (a.fused && ((cf == 0.f && kvf == row_b) || (cf == 1.f && kvf == row_e)));
+            if (!single) {
+                N_skip = !p.multi;
+                // (arithmetic, not `c == 1 ? a.end : a.begin`: a select between two FIELDS of the by-value argument struct becomes a
+                //  select between their addresses and hipcc then keeps the whole struct in scratch)
+                const bool both = cf != 0.f && cf != 1.f;
+                const int side = row_b + (cf == 1.f ? 1 : 0) * (row_e - row_b);       // the end-point row of a one-sided frame
+                const int fz = a.fused ? 1 : 0;
+                if (a.mode == AID_MODE_OUTER) {
+                    N_nseg = fz + (both ? 2 : 1);
+                    const int first = both ? row_b : side;
+                    seg0 = fz * kvf + (1 - fz) * first;
+                    seg1 = fz * first + (1 - fz) * row_e;
+                    if (both) { N_wb = 1.f - cf; N_we = cf; N_park = fz ? 1 : -1; N_swap = fz + 1; }
+                } else {
+                    N_nseg = fz + 1;
+                    const int mix = both ? N_fr : side;
+                    seg0 = fz * kvf + (1 - fz) * mix;
+                    seg1 = mix;
+                    N_t2 = both ? (fz ? 2 : 1) : 0;
+                }
             }
         }
-    }
+        // one descriptor per tensor; the key / value ROW of a segment and the head ride in the scalar offset (tensors < 2 GB)
+        const int kh = N_h * D * 2, vh = N_h * D * a.ldvt * 2;
+        N_ks0 = seg0 * (int)a.k_fs * 2 + kh;  N_ks1 = seg1 * (int)a.k_fs * 2 + kh;  N_ks2 = row_e * (int)a.k_fs * 2 + kh;
+        N_vs0 = seg0 * (int)a.vt_fs * 2 + vh; N_vs1 = seg1 * (int)a.vt_fs * 2 + vh; N_vs2 = row_e * (int)a.vt_fs * 2 + vh;
+    };
+    int fr, h, q0, nseg, ks0, ks1, ks2, vs0, vs1, vs2, t2mask, park_at, swap_at, NT;
+    float w_b, w_e;
+    auto adopt = [&]() __attribute__((always_inline)) {
+        fr = N_fr; h = N_h; q0 = N_q0; nseg = N_nseg; ks0 = N_ks0; ks1 = N_ks1; ks2 = N_ks2; vs0 = N_vs0; vs1 = N_vs1; vs2 = N_vs2;
+        t2mask = N_t2; park_at = N_park; swap_at = N_swap; w_b = N_wb; w_e = N_we;
+        NT = nseg * nt;
+    };
+    plan(vblock(0));
+    if (N_skip) return;                                         // (split launches are never persistent)
+    adopt();
 
     // ---- Q fragments (B operand of the swapped product) -----------------------------------------
     T8 qf[4];
-    {
-        const int qr = min(q0 + l31, a.s - 1);                  // rows past the end are clamped, never stored
-        const T* qrow = reinterpret_cast<const T*>(a.q) + (int64_t)fr * a.q_fs + (int64_t)qr * a.ldq + h * D;
+    auto scale_q = [&]() __attribute__((always_inline)) {       // generic callers: fold softmax_scale * log2(e) into Q here (one extra
+        if (!a.q_prescaled) {                                   // rounding; the processor path does it in the q projection's epilogue)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = *reinterpret_cast<const T8*>(qrow + ks * 16 + hi * 8);
-            if (!a.q_prescaled) {
+            for (int ks = 0; ks < 4; ++ks) {
                 f32x8 t = up8<T>(qf[ks]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] *= p.c2;
                 qf[ks] = cvt8<T>(t);
             }
         }
+    };
+    {                                                           // the first item's rows: straight from global memory
+        const int qr = min(q0 + l31, a.s - 1);                  // rows past the end are clamped, never stored
+        const T* qrow = reinterpret_cast<const T*>(a.q) + (int64_t)fr * a.q_fs + (int64_t)qr * a.ldq + h * D;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const T8*>(qrow + ks * 16 + hi * 8);
+        scale_q();
     }
 
     // ---- DMA addressing: this wave's piece (8 rows x 128 B) of every K tile and of every V^T tile ------------
-    // one descriptor per tensor (this head's columns / rows); the key / value ROW of a segment goes into the scalar offset
-    // (attn_pp_supported: the tensors are below 2 GB)
-    const T* Kg = reinterpret_cast<const T*>(a.k) + h * D;
-    const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)(h * D) * a.ldvt;
-    const Rsrc rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Kg), 0, 0x7fffffff, 0x00020000);
-    const Rsrc rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Vg), 0, 0x7fffffff, 0x00020000);
-    const int nt = a.l / PKT;                                   // tiles per segment
-    const int NT = nseg * nt;                                   // tiles of this workgroup's stream
-    const int ks0 = seg0 * (int)a.k_fs * 2, ks1 = seg1 * (int)a.k_fs * 2, ks2 = seg2 * (int)a.k_fs * 2;
-    const int vs0 = seg0 * (int)a.vt_fs * 2, vs1 = seg1 * (int)a.vt_fs * 2, vs2 = seg2 * (int)a.vt_fs * 2;
-    // INNER: the interpolated keys / values live in their own tensors (same layout, row = frame)
-    const T* K2g = reinterpret_cast<const T*>(a.k2) + h * D;
-    const T* V2g = reinterpret_cast<const T*>(a.vt2) + (int64_t)(h * D) * a.ldvt;
-    const Rsrc rk2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(K2g), 0, 0x7fffffff, 0x00020000);
-    const Rsrc rv2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(V2g), 0, 0x7fffffff, 0x00020000);
+    // one descriptor per tensor (attn_pp_supported: below 2 GB); INNER: the interpolated keys / values live in their own tensors
+    const Rsrc rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.k), 0, 0x7fffffff, 0x00020000);
+    const Rsrc rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.vt), 0, 0x7fffffff, 0x00020000);
+    const Rsrc rk2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.k2), 0, 0x7fffffff, 0x00020000);
+    const Rsrc rv2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.vt2), 0, 0x7fffffff, 0x00020000);
+    // the NEXT item's Q rows wait in LDS behind the ring (8 waves x 4 KB, already in fragment order: piece ks of a wave = its 64 lanes'
+    // 16 B of k-step ks), fetched by DMA while the current item runs — no registers held for them
+    const Rsrc rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.q), 0, 0x7fffffff, 0x00020000);
+    char* const qlds = smem + 2 * PNS * PTILE + wave * 4096;
+    auto dma_q_next = [&]() __attribute__((always_inline)) {
+        const int qr = min(N_q0 + l31, a.s - 1);
+        const int vo = qr * (a.ldq * 2) + hi * 16;
+        const int so = (int)(((int64_t)N_fr * a.q_fs + N_h * D) * 2);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(qlds + ks * 1024), 16, vo, so + ks * 32, 0, 0);
+    };
     const int prow = 8 * wave + (lane >> 3);                    // tile row this lane fetches
     const int pch = (lane & 7) ^ ((prow >> 1) & 7);             // logical 16-B chunk stored at slot lane & 7 (XOR swizzle)
     const int kvo = prow * (a.ldk * 2) + pch * 16;              // + key0 * ldk * 2 (scalar)
@@ -201,12 +239,19 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         dv += PKT * 2;
         if (--dleft == 0) {                                     // next segment (arithmetic on values, see above)
             ++dseg;
-            dk = ks1 + (dseg >= 2 ? ks2 - ks1 : 0);
-            dv = vs1 + (dseg >= 2 ? vs2 - vs1 : 0);
-            d2 = ((t2mask >> dseg) & 1) != 0;
             dleft = nt;
+            if (dseg < nseg) {
+                dk = ks1 + (dseg >= 2 ? ks2 - ks1 : 0);
+                dv = vs1 + (dseg >= 2 ? vs2 - vs1 : 0);
+                d2 = ((t2mask >> dseg) & 1) != 0;
+            } else {                                            // the stream runs on into the first segment of the planned item
+                dk = N_ks0;
+                dv = N_vs0;
+                d2 = (N_t2 & 1) != 0;
+            }
         }
     };
+    bool has_next = false;
 
     // ---- fragment read offsets: K rows with key bits 2 <-> 3 swapped (so P comes out in B-operand order), V^T rows = channels
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
@@ -304,12 +349,12 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         else             wait_vm<0>();
     };
     auto vslot = [&](int t) __attribute__((always_inline)) {
-        const bool issue = t + LEAD < NT;
+        const bool issue = has_next || t + LEAD < NT;
 #ifdef AID_ABLATIONS
         if (p.abl & 1) {                                        // 1: no VALU work in the V slot
             if (!(p.abl & 2) && issue) dma_next((t + LEAD) & (PNS - 1));
             fresh = false;
-            retire(NT - 4 - t);
+            retire(has_next ? 3 : NT - 4 - t);
             return;
         }
 #endif
@@ -361,7 +406,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             for (int e = 0; e < 4; ++e) lsum = dot2_ones<T>(w4[e], lsum);
         }
         if (issue) wait_vm<6>();                                // steady state: the three tiles behind t + 3 stay in flight
-        else       retire(NT - 4 - t);
+        else       retire(NT - 4 - t);                          // (last item: the stream has run out)
     };
 
     // Segment boundaries of a two-sided frame.  S(t) of the next segment's first tile is in `sc` and PV(t - 1) closed the segment
@@ -394,6 +439,37 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[b][r] += back;
         if (park_at < 0) fresh = true;                          // pure OUTER: the end side starts from the empty state
+    };
+
+    // O / l of the finished item; lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3}
+    auto finish = [&]() __attribute__((always_inline)) {
+#ifdef AID_ABLATIONS
+        if (p.abl & (16 | 32)) {                                // slot timing / workgroup timeline instead of the result
+            if (lane == 0 && q0 < a.s) {
+                float* dbg = reinterpret_cast<float*>(reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q0 * a.ldo + h * D);
+                if (p.abl & 16) for (int i = 0; i < 4; ++i) dbg[i] = tacc[i] / (float)(NT - 1);
+                else { tl[4] = clock64(); for (int i = 1; i < 5; ++i) dbg[i - 1] = (float)(tl[i] - tl[0]); }
+            }
+            return;
+        }
+#endif
+        const float inv = w_e / (lsum + other_half(lsum));      // (w_e = 1 unless this frame mixes two sides)
+        const int q = q0 + l31;
+        if (q < a.s) {
+            const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
+            T* orow = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q * a.ldo + h * D;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dv_ = 32 * d + 8 * g + 4 * hi;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (o[d][4 * g + e] * inv + po[d][4 * g + e]) * osc;      // po: the begin side, or zero
+                    if (a.accumulate) v += up4<T>(*reinterpret_cast<const T4*>(orow + dv_));
+                    *reinterpret_cast<T4*>(orow + dv_) = cvt4<T>(v);
+                }
+        }
     };
 
     // fence between a slot's last MFMAs and the VALU code of the next slot that reads their results (20 wait states; the hazard
@@ -444,82 +520,64 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 #ifdef AID_ABLATIONS
     if (p.abl & 32) tl[3] = clock64();
 #endif
-    // One pass per key segment (`nounroll`: one copy of the body); inside, eight tiles per trip: t & 7 — the ring stage of every DMA
-    // and fragment read — is a compile-time constant in each copy (segments of a multi-segment frame are multiples of eight tiles).
+    // Items: for (;;) { plan the next item, request its Q rows; walk this item's tiles; finish it; adopt the next }.  Every tile t of an
+    // item gets V(t) and M(t + 1); behind the LAST tile "t + 1" is tile 0 of the next item (its Q fragments are read back from LDS
+    // right before that M slot) or, for the workgroup's last item, stale ring bytes whose scores nobody reads.
 #pragma nounroll
-    for (int sgi = 0; sgi < nseg; ++sgi) {
-        if (sgi == park_at) park();
-        if (sgi == swap_at) swap_sides();
-        const int t_end = min((sgi + 1) * nt, NT - 1);          // V(t) + M(t + 1) for the tiles t of this segment; the stream's last
-        for (int t8 = sgi * nt; t8 < t_end; t8 += 8) {          // tile is finished behind the loop
+    for (int j = 0;; ++j) {
+        const int vbn = vblock(j + 1);
+        has_next = vbn < n_items;
+        if (has_next) {
+            plan(vbn);
+            dma_q_next();
+        }
+        // One pass per key segment (`nounroll`: one copy of the body); inside, eight tiles per trip: t & 7 — the ring stage of every
+        // DMA and fragment read — is a compile-time constant in each copy (segments of a multi-segment frame, and every item of a
+        // persistent launch, are whole trips).
+#pragma nounroll
+        for (int sgi = 0; sgi < nseg; ++sgi) {
+            if (sgi == park_at) park();
+            if (sgi == swap_at) swap_sides();
+            const int t_end = (sgi + 1) * nt;
+            for (int t8 = sgi * nt; t8 < t_end; t8 += 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int t = t8 + j;
-                if (t >= t_end) break;
-                PP_STAMP(3);
-                vslot(t);
-                PP_STAMP(0);
-                slot_barrier();
-                PP_STAMP(1);
-                mslot(j, (j + 2) & 7);                          // (the K(t + 2) reads past the last tile fetch stale ring bytes, unused)
-                settle();
-                PP_STAMP(2);
-                slot_barrier();
+                for (int i = 0; i < 8; ++i) {
+                    const int t = t8 + i;
+                    if (t >= t_end) break;
+                    PP_STAMP(3);
+                    vslot(t);
+                    if (has_next && t == NT - 1) {              // the M slot behind the item's last tile forms the next item's S(0):
+#pragma unroll                                                  // its Q rows, and a zero row reference like a fresh workgroup's
+                        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const T8*>(qlds + ks * 1024 + lane * 16);
+                        scale_q();
+                        m = 0.f;                                // (the finished item needs O and the row sums only)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) cneg[r] = 0.f;
+                        asm volatile("" : "+v"(cneg));
+                    }
+                    PP_STAMP(0);
+                    slot_barrier();
+                    PP_STAMP(1);
+                    mslot(i, (i + 2) & 7);
+                    settle();
+                    PP_STAMP(2);
+                    slot_barrier();
+                }
             }
         }
+        finish();
+        if (!has_next) break;
+        // the next item: its S(0) is in `sc`; everything else starts over
+        fresh = true;
+        lsum = 0.f;
+        pl = 0.f;
+        pm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; po[0][r] = 0.f; po[1][r] = 0.f; }
+        adopt();
+        dseg = 0;                                               // the DMA stream is LEAD tiles into this item's first segment already
     }
-    vslot(NT - 1);
-    slot_barrier();
-    {                                                           // O += V^T(NT - 1) P(NT - 1)^T
-        const int so = ((NT - 1) & 7) * PTILE;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) vf[i >> 1][i & 1] = *reinterpret_cast<const T8*>(smem + vad[i >> 1] + so + (i & 1) * 4096);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int d = 0; d < 2; ++d) o[d] = mfma32(vf[kk][d], pf[kk], o[d]);
-        }
-    }
-    settle();
-    slot_barrier();
     if (grp == 0) slot_barrier();                               // both groups pass the same number of barriers
-
-    // ---- finish: O / l, lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3} ----------------------
-#ifdef AID_ABLATIONS
-    if (p.abl & 32) {
-        tl[4] = clock64();
-        if (lane == 0 && q0 < a.s) {
-            float* dbg = reinterpret_cast<float*>(reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q0 * a.ldo + h * D);
-            for (int i = 1; i < 5; ++i) dbg[i - 1] = (float)(tl[i] - tl[0]);
-            dbg[4] = (float)(tl[0] & 0xffffff);
-        }
-        return;
-    }
-    if (p.abl & 16) {
-        if (lane == 0 && q0 < a.s) {
-            float* dbg = reinterpret_cast<float*>(reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q0 * a.ldo + h * D);
-            for (int i = 0; i < 4; ++i) dbg[i] = tacc[i] / (float)(NT - 1);
-        }
-        return;
-    }
-#endif
-    const float inv = w_e / (lsum + other_half(lsum));          // (w_e = 1 unless this frame mixes two sides)
-    const int q = q0 + l31;
-    if (q < a.s) {
-        const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
-        T* orow = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q * a.ldo + h * D;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dv = 32 * d + 8 * g + 4 * hi;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (o[d][4 * g + e] * inv + po[d][4 * g + e]) * osc;      // po: the begin side, or zero
-                if (a.accumulate) v += up4<T>(*reinterpret_cast<const T4*>(orow + dv));
-                *reinterpret_cast<T4*>(orow + dv) = cvt4<T>(v);
-            }
-    }
 }
 
 }  // namespace
@@ -540,7 +598,7 @@ hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) 
     p.nqb = (a.s + 255) / 256;
     p.c2 = a.softmax_scale * 1.4426950408889634f;
     p.abl = tune(TUNE_ATTN_RES_CHUNKS) > 100 ? tune(TUNE_ATTN_RES_CHUNKS) - 100 : 0;      // development builds only
-    const size_t smem = (size_t)PNS * PSTAGE;
+    const size_t smem = (size_t)PNS * PSTAGE + 8 * 4096;        // ring + the next item's Q rows
     static PerDevice<bool> attr_set[2];
     const int ti = a.dtype == AID_DTYPE_F16 ? 0 : 1;
     bool* done = attr_set[ti].slot();
@@ -552,7 +610,21 @@ hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) 
         if (e != hipSuccess) return e;
         *done = true;
     }
-    const int grid = p.nqb * a.n_frames * a.heads;
+    const int items = p.nqb * a.n_frames * a.heads;
+    // persistent: the kernel owns every frame of the call (no early exits), every item is whole 8-tile trips, more items than CUs
+    static PerDevice<int> cus;
+    int* ncu = cus.slot();
+    if (!ncu) return hipErrorInvalidDevice;
+    if (*ncu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) *ncu = 256;
+    }
+    const int knob = tune(TUNE_ATTN_PIPE);                      // development: 0 = one item per workgroup
+    // (measured: plain S = 4096 582 -> 560 us, S = 1024 108 -> 94, inner 808 -> 800 / 129 -> 122; the 3 : 1 item mix of an OUTER call is
+    //  balanced as well by the hardware's dynamic dispatch as by the static snake order: 1048 vs 1047, 160 vs 160 — one item per workgroup)
+    const bool uniform = a.mode != AID_MODE_OUTER || knob == 1;
+    p.persist = ((multi || a.mode == AID_MODE_PLAIN) && (a.l / PKT) % 8 == 0 && items > *ncu && *ncu % 8 == 0 && knob != 0 && uniform) ? 1 : 0;
+    const int grid = p.persist ? *ncu : items;
     if (ti == 0) hipLaunchKernelGGL(aid_attn_pp_kernel<f16>, dim3(grid), dim3(512), smem, stream, p);
     else         hipLaunchKernelGGL(aid_attn_pp_kernel<bf16>, dim3(grid), dim3(512), smem, stream, p);
     return hipGetLastError();

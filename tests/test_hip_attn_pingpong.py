@@ -190,18 +190,46 @@ def test_accumulate_scales_kv_map_and_determinism(tuning):
 
 
 def test_default_rule_for_the_pingpong_kernel(tuning):
-    """No knob: fused OUTER calls from 1024 keys, every other call from 2048 keys run on the ping-pong kernel (calls with several
-    segments per frame: multiples of 512 keys); shorter ones do not."""
+    """No knob: fused OUTER and INNER calls from 1024 keys, PLAIN and pure OUTER calls from 2048 keys run on the ping-pong kernel (calls
+    with several segments per frame: multiples of 512 keys); shorter ones do not."""
     dtype, h = torch.bfloat16, 1
     for l, mode, fused, want in ((2048, "plain", False, True), (1024, "plain", False, False), (2048, "outer", True, True),
                                  (1024, "outer", True, True), (512, "outer", True, False), (2048, "outer", False, True),
-                                 (2048, "inner", True, True), (1024, "inner", True, False), (2048, "inner", False, True),
+                                 (2048, "inner", True, True), (1024, "inner", True, True), (512, "inner", True, False), (2048, "inner", False, True),
                                  (2112, "outer", True, False), (2112, "plain", False, True)):
         q, k, v, vt = _inputs(3, 32, l, h, dtype, seed=l)
         coef = torch.tensor([0.0, 0.5, 1.0])
         ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=fused,
                      coef=None if mode == "plain" else coef.to(DEV), begin=0, end=2)
         assert ("aid_attn_pp" in ops.last_attn_variant()) == want, (l, mode, fused, ops.last_attn_variant())
+
+
+@pytest.mark.parametrize("mode,fused", [("outer", True), ("inner", True), ("inner", False), ("outer", False), ("plain", False)])
+def test_persistent_workgroups_at_the_sdxl_level_shape(mode, fused, tuning):
+    """S = 1024, 7 AID frames + 7 riders, 20 heads = 1120 items on 256 persistent workgroups (ATTN_PIPE = 1 forces the persistent walk
+    for the mixed OUTER call too): the tile stream runs across item boundaries, the next item's Q rows come back from LDS, parked /
+    swapped states start over per item.  Against the program-order kernel (itself held against the oracle) on the whole tensor."""
+    dtype, n, s, h = torch.bfloat16, 7, 1024, 20
+    q, k, v, vt = _inputs(2 * n, s, s, h, dtype, seed=31)
+    coef = torch.from_numpy(O.beta_coefs(n, 50, 50)).float()
+    coef[0], coef[-1] = 0, 1
+    cd = torch.cat([coef.to(dtype).float(), -torch.ones(n)]).to(DEV)
+    args = dict(l=s, mode=mode, fused=fused, coef=None if mode == "plain" else cd, begin=0, end=n - 1, n_plain=0 if mode == "plain" else n)
+    qd, kd, vd = q.to(DEV), k.to(DEV), vt.to(DEV)
+    tuning("ATTN_V2", 1)
+    tuning("ATTN_PIPE", 1)
+    o = ops.attn_fwd(qd, kd, vd, h, **args)
+    assert "aid_attn_pp" in ops.last_attn_variant() and torch.isfinite(o).all()
+    o2 = ops.attn_fwd(qd, kd, vd, h, **args)
+    assert torch.equal(o, o2)                                   # deterministic
+    tuning("ATTN_PIPE", 0)                                      # one item per workgroup
+    o1 = ops.attn_fwd(qd, kd, vd, h, **args)
+    assert torch.equal(o, o1)                                   # the walk order does not change a bit
+    tuning("ATTN_V2", 0)
+    ref = ops.attn_fwd(qd, kd, vd, h, **args)
+    assert "aid_attn_pp" not in ops.last_attn_variant()
+    for f in range(2 * n):
+        assert rel_l2(to_np64(o[f]), to_np64(ref[f])) < TOL[dtype], f
 
 
 def test_full_size_sdxl_levels_sampled_rows(tuning):

@@ -47,8 +47,10 @@ def test_sgpr_spills_are_bounded():
     slots in kernels that are VALU-issue bound, and a jump in the count means a refactor pushed scalar state (segment
     pointers, descriptors) out of the 102 SGPRs.  The GEMM and LayerNorm kernels spill none; the attention kernel's
     three-segment variants spill up to 30 (measured at this commit; they sit outside the tile loop: pointers of the
-    segments not being walked).  VERDICT r2 weak #10."""
-    for obj, bound in (("aid_gemm", 0), ("aid_norm", 0), ("aid_attn_pp", 8), ("aid_attn", 32)):
+    segments not being walked); the ping-pong kernel keeps two item records (the one it computes, the one it planned) and spills
+    82 of them — none inside the tile loop (checked in the ISA; an earlier version with spills in the loop was 9 % slower).
+    VERDICT r2 weak #10."""
+    for obj, bound in (("aid_gemm", 0), ("aid_norm", 0), ("aid_attn_pp", 96), ("aid_attn", 32)):
         for sym, r in _table(obj).items():
             assert r["sgpr_spill"] <= bound, (obj, sym, r)
 
@@ -81,7 +83,7 @@ def test_attention_variants_keep_the_waves_per_simd_the_launcher_assumes():
 
 def test_pingpong_attention_keeps_two_waves_per_simd():
     """The ping-pong kernel's premise is one wave of each group per SIMD (8 waves per CU): <= 256 registers per wave with the parked
-    state of a two-sided frame and the -m block in them (232 at this commit; the park / swap code inside the unrolled tile loop had it at 256 + 14
+    state of a two-sided frame and the -m block in them (238 at this commit; the park / swap code inside the unrolled tile loop had it at 256 + 14
     spills, and a select between two by-value argument fields had put 416 B per lane into scratch)."""
     for sym, r in _table("aid_attn_pp").items():
         if "aid_attn_pp_kernel" in sym:
