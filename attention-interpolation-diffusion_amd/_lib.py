@@ -25,7 +25,7 @@ IP_NONE, IP_SAME, IP_PLAIN = 0, 1, 2
 ABI_SYMBOLS = (
     "aid_gemm_nt", "aid_layernorm", "aid_ln_stats", "aid_ln_fold", "aid_attn_fwd", "aid_lerp_kv", "aid_processor_workspace_bytes", "aid_processor_fwd",
     "aid_abi_version", "aid_strerror", "aid_last_attn_variant", "aid_last_gemm_variant", "aid_device_info",
-    "aid_profile_begin", "aid_profile_end", "aid_set_tuning",
+    "aid_profile_begin", "aid_profile_end", "aid_set_tuning", "aid_get_tuning",
 )
 
 
@@ -137,6 +137,8 @@ def load() -> C.CDLL:
     lib.aid_processor_fwd.argtypes = [C.POINTER(AidProcessorArgs), C.c_void_p]
     lib.aid_set_tuning.restype = C.c_int
     lib.aid_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    lib.aid_get_tuning.restype = C.c_int
+    lib.aid_get_tuning.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
     lib.aid_profile_begin.restype = C.c_int
     lib.aid_profile_end.restype = C.c_int
     lib.aid_profile_end.argtypes = [C.POINTER(AidProfileEntry), C.c_int]

@@ -57,6 +57,15 @@ struct ProfScope {          // records an event pair around one launch when prof
 // ---- tuning knobs (aid_kernels.hpp: enum Tune) -----------------------------------------------------
 const char* const g_tune_names[aid::TUNE_COUNT] = {"GEMM_VARIANT", "GEMM_PP", "GEMM_TRI", "ATTN_NW", "ATTN_QB", "ATTN_PIPE",
                                                    "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2"};
+// Largest value a knob accepts.  Every accepted value selects between kernels / launch shapes that compute THE SAME RESULT (the parity
+// suite runs under each of them); values beyond the range are refused by aid_set_tuning and ignored in the environment.  The timing
+// ablations (kernels that skip work, "results are garbage") exist only in development builds (-DAID_ABLATIONS, tools/dev/Makefile ->
+// tools/dev/libaid_abl.so) and are addressed through the same table there.
+#ifdef AID_ABLATIONS
+const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1};
+#else
+const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1};
+#endif
 struct TuneTable {
     int v[aid::TUNE_COUNT];
     TuneTable() {                               // runs once, when the library is loaded
@@ -64,7 +73,8 @@ struct TuneTable {
             char name[64];
             snprintf(name, sizeof(name), "AID_%s", g_tune_names[i]);
             const char* e = getenv(name);
-            v[i] = (e && *e) ? atoi(e) : -1;
+            const int x = (e && *e) ? atoi(e) : -1;
+            v[i] = (x < 0 || x > g_tune_max[i]) ? -1 : x;
         }
     }
 };
@@ -179,7 +189,19 @@ int aid_set_tuning(const char* name, int value) {
     if (!strncmp(name, "AID_", 4)) name += 4;
     for (int i = 0; i < aid::TUNE_COUNT; ++i)
         if (!strcmp(name, g_tune_names[i])) {
+            if (value > g_tune_max[i]) return AID_ERR_ARG;      // no value may change results (see g_tune_max)
             g_tune.v[i] = value < 0 ? -1 : value;
+            return AID_OK;
+        }
+    return AID_ERR_ARG;
+}
+
+int aid_get_tuning(const char* name, int* value) {
+    if (!name || !value) return AID_ERR_ARG;
+    if (!strncmp(name, "AID_", 4)) name += 4;
+    for (int i = 0; i < aid::TUNE_COUNT; ++i)
+        if (!strcmp(name, g_tune_names[i])) {
+            *value = g_tune.v[i];
             return AID_OK;
         }
     return AID_ERR_ARG;

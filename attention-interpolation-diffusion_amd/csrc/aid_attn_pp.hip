@@ -43,7 +43,9 @@ struct AttnPPParams {
     int32_t multi;                      // 1: this launch runs every frame of the call (it is the only launch)
     int32_t persist;                    // 1: one workgroup per CU walks several items (every item is whole 8-tile trips)
     float   c2;                         // softmax_scale * log2(e)
-    int32_t abl;                        // development builds (-DAID_ABLATIONS): timing ablations, results are garbage
+#ifdef AID_ABLATIONS
+    int32_t abl;                        // development builds only: timing ablations, results are garbage
+#endif
 };
 
 typedef __amdgpu_buffer_rsrc_t Rsrc;
@@ -597,7 +599,9 @@ hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) 
     p.multi = multi ? 1 : 0;
     p.nqb = (a.s + 255) / 256;
     p.c2 = a.softmax_scale * 1.4426950408889634f;
-    p.abl = tune(TUNE_ATTN_RES_CHUNKS) > 100 ? tune(TUNE_ATTN_RES_CHUNKS) - 100 : 0;      // development builds only
+#ifdef AID_ABLATIONS
+    p.abl = tune(TUNE_ATTN_RES_CHUNKS) > 100 ? tune(TUNE_ATTN_RES_CHUNKS) - 100 : 0;
+#endif
     const size_t smem = (size_t)PNS * PSTAGE + 8 * 4096;        // ring + the next item's Q rows
     static PerDevice<bool> attr_set[2];
     const int ti = a.dtype == AID_DTYPE_F16 ? 0 : 1;

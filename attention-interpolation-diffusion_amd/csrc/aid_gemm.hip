@@ -948,7 +948,9 @@ struct PingPongX : PingPong<T> {
     using PP::ra; using PP::rb; using PP::avo; using PP::bvo;
     f32x16 accx;
     int xoff, xx, xvo;
+#ifdef AID_ABLATIONS
     int abl_ = 0;               // development builds: 4 = epilogue without the global stores, 8 = without the staging pass
+#endif
 
     __device__ __forceinline__ void init(char* smem_) {
         PP::init(smem_);
@@ -1065,17 +1067,22 @@ struct PingPongX : PingPong<T> {
     // Whole tile: four copies of (K loop + epilogue) — fb[WR] must be a compile-time register choice and the operand order
     // a compile-time choice; the epilogue sits INSIDE each copy so that no accumulator crosses a control-flow merge (with a
     // common epilogue behind the four loops hipcc spilled 80 accumulator registers at the join).
-    __device__ __forceinline__ void run_tile(const GemmDesc& P, T* C, int batch, int m0, int n0, int abl = 0) {
+    __device__ __forceinline__ void run_tile(const GemmDesc& P, T* C, int batch, int m0, int n0
+#ifdef AID_ABLATIONS
+                                             , int abl = 0
+#endif
+                                             ) {
         const int nk = P.k / 64;
-        abl_ = abl;
         const T* R = P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)batch * P.stride_c : nullptr;
         const float* st = P.ln_stats ? P.ln_stats + 2 * (int64_t)batch * P.stride_stats : nullptr;
         if (P.trans_rows) {
             if (wr == 0) { mac_x<0, true>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
             else         { mac_x<1, true>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
         } else {
-            // (abl: timing ablations of development builds — 1 = no epilogue, 2 = no K loop; one call site per instantiation:
-            //  a second `mac_x<1, false>` call elsewhere fails to instantiate in hipcc's host pass)
+#ifdef AID_ABLATIONS
+            // (timing ablations of development builds — 1 = no epilogue, 2 = no K loop; one call site per instantiation: a second
+            //  `mac_x<1, false>` call elsewhere fails to instantiate in hipcc's host pass)
+            abl_ = abl;
             if (wr == 0) { if (!(abl & 2)) mac_x<0, false>(0, nk); if (!(abl & 1)) store_tile(P, C, m0, n0, R, st); }
             else         { if (!(abl & 2)) mac_x<1, false>(0, nk); if (!(abl & 1)) store_tile(P, C, m0, n0, R, st); }
             if (abl & 1) {
@@ -1085,6 +1092,10 @@ struct PingPongX : PingPong<T> {
                     for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
                 asm volatile("" ::"v"(accx));
             }
+#else
+            if (wr == 0) { mac_x<0, false>(0, nk); store_tile(P, C, m0, n0, R, st); }
+            else         { mac_x<1, false>(0, nk); store_tile(P, C, m0, n0, R, st); }
+#endif
         }
     }
 
@@ -1342,7 +1353,11 @@ static_assert((288 * 32) % 512 == 0 && (256 * 36) % 512 == 0, "C rows divide ove
 static_assert(Engine<bf16, 128, 128, 64, 4, 2, 4>::SMEM <= PingPongX<bf16>::SMEMX, "side tiles use the big tile's LDS");
 
 template <typename T>
-__global__ __launch_bounds__(512) void aid_gemm_nt_ppx_kernel(const GemmGroup g, const GemmSide sd, const int abl) {
+__global__ __launch_bounds__(512) void aid_gemm_nt_ppx_kernel(const GemmGroup g, const GemmSide sd
+#ifdef AID_ABLATIONS
+                                                              , const int abl      // development builds only: timing ablations
+#endif
+                                                              ) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if ((int)blockIdx.x < sd.pad_tiles) {                          // side problems first (see aid_gemm_nt_pp_kernel)
         const int u = blockIdx.x;
@@ -1585,8 +1600,12 @@ static hipError_t launch_ppx(GemmGroup& g, hipStream_t stream, const GemmSide& s
         if (e != hipSuccess) return e;
         *done = true;
     }
-    const int abl = tune(TUNE_GEMM_PP) >= 8 ? tune(TUNE_GEMM_PP) - 8 : 0;     // development builds only (AID_ABLATIONS)
+#ifdef AID_ABLATIONS
+    const int abl = tune(TUNE_GEMM_PP) >= 8 ? tune(TUNE_GEMM_PP) - 8 : 0;
     hipLaunchKernelGGL(aid_gemm_nt_ppx_kernel<T>, dim3(sd.pad_tiles + tiles), dim3(512), PingPongX<T>::SMEMX, stream, g, sd, abl);
+#else
+    hipLaunchKernelGGL(aid_gemm_nt_ppx_kernel<T>, dim3(sd.pad_tiles + tiles), dim3(512), PingPongX<T>::SMEMX, stream, g, sd);
+#endif
     return hipGetLastError();
 }
 

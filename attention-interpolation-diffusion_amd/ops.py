@@ -278,6 +278,14 @@ def set_tuning(name: str, value: int = -1) -> None:
     _lib.check(_lib.load().aid_set_tuning(name.encode(), int(value)), f"aid_set_tuning({name})")
 
 
+def get_tuning(name: str) -> int:
+    """Current value of a development knob (``aid_get_tuning``); -1 = the launch heuristics decide."""
+    import ctypes
+    v = ctypes.c_int(0)
+    _lib.check(_lib.load().aid_get_tuning(name.encode(), ctypes.byref(v)), f"aid_get_tuning({name})")
+    return int(v.value)
+
+
 def last_attn_variant() -> str:
     return _lib.load().aid_last_attn_variant().decode()
 

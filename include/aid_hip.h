@@ -300,8 +300,12 @@ const char* aid_last_gemm_variant(void);
 /* Development / tuning knobs (kernel-variant choices the launch heuristics normally make: "GEMM_VARIANT", "GEMM_PP",
  * "ATTN_NW", "ATTN_RES", ... — the list is in csrc/aid_kernels.hpp).  The table is filled ONCE when the library is
  * loaded, from environment variables AID_<NAME>; this call changes an entry at run time (value < 0 = back to the
- * heuristic).  Nothing on the launch path reads the environment.  Returns AID_ERR_ARG for an unknown name. */
+ * heuristic).  Nothing on the launch path reads the environment.  Every value a knob accepts selects among kernels that compute the
+ * same result; a value outside a knob's range is refused (AID_ERR_ARG) here and ignored in the environment — no setting can make the
+ * library skip work.  Returns AID_ERR_ARG for an unknown name. */
 int aid_set_tuning(const char* name, int value);
+/* current value of a knob (-1 = the launch heuristics decide) */
+int aid_get_tuning(const char* name, int* value);
 /* device properties of the current device: returns AID_OK and fills what is non-NULL */
 int aid_device_info(int* n_cu, int* clock_khz, char* arch /* >= 32 bytes */);
 

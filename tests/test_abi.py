@@ -186,3 +186,57 @@ def test_integration_doc_stub_matches_the_header():
     stub = doc[doc.index("class AidProcessorArgs(C.Structure)"):doc.index("lib.aid_processor_workspace_bytes.restype")]
     names = re.findall(r'\("(\w+)", C\.', stub)
     assert names == [f for f, _ in _lib.AidProcessorArgs._fields_]
+
+
+# ---- no setting may change results ----------------------------------------------------
+KNOB_MAX = {"GEMM_VARIANT": 31, "GEMM_PP": 3, "GEMM_TRI": 1, "ATTN_NW": 8, "ATTN_QB": 2, "ATTN_PIPE": 1, "ATTN_RES": 1,
+            "ATTN_RES_CHUNKS": 64, "ATTN_ORDER": 1, "ATTN_V2": 1}
+
+
+def test_tuning_knobs_refuse_values_outside_their_range():
+    """The timing ablations of development builds were addressed as GEMM_PP >= 8 / ATTN_RES_CHUNKS > 100: the product library refuses
+    such values (and has no code behind them)."""
+    from aid_amd import ops
+    lib = _lib.load()
+    for name, top in KNOB_MAX.items():
+        assert lib.aid_set_tuning(name.encode(), top + 1) != 0, name
+        assert ops.get_tuning(name) == -1, name
+        ops.set_tuning(name, top)
+        assert ops.get_tuning(name) == top
+        ops.set_tuning(name, -1)
+        assert ops.get_tuning(name) == -1
+    assert lib.aid_set_tuning(b"GEMM_PP", 9) != 0 and lib.aid_set_tuning(b"ATTN_RES_CHUNKS", 116) != 0
+    assert lib.aid_set_tuning(b"NO_SUCH_KNOB", 1) != 0
+
+
+def test_environment_cannot_select_an_ablation():
+    """AID_GEMM_PP=9 / AID_ATTN_RES_CHUNKS=116 in the environment (the old ablation addresses) are ignored at library load."""
+    import subprocess, sys
+    env = dict(os.environ, AID_GEMM_PP="9", AID_ATTN_RES_CHUNKS="116", AID_ATTN_NW="8")
+    code = ("import sys; sys.path.insert(0, %r); import aid_amd; from aid_amd import ops; "
+            "print(ops.get_tuning('GEMM_PP'), ops.get_tuning('ATTN_RES_CHUNKS'), ops.get_tuning('ATTN_NW'))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["-1", "-1", "8"]
+
+
+def test_product_library_has_no_ablation_code():
+    """No kernel of libaid_hip.so takes an ablation word, and the development build does not ship next to it."""
+    import subprocess
+    pkg = os.path.dirname(_lib.LIB_PATH)
+    assert not os.path.exists(os.path.join(pkg, "libaid_abl.so"))
+    txt = subprocess.run(["strings", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "ablation" not in txt.lower() and "AID_ABLATIONS" not in txt
+    for src in ("aid_gemm.hip", "aid_attn_pp.hip", "aid_attn.hip"):
+        body = open(os.path.join(_lib.CSRC_DIR, src)).read()
+        out, depth = [], 0                                  # every mention of `abl` sits inside #ifdef AID_ABLATIONS
+        for line in body.splitlines():
+            t = line.strip()
+            if t.startswith("#ifdef AID_ABLATIONS"):
+                depth += 1
+            elif depth and t.startswith("#if"):
+                depth += 1
+            elif depth and t.startswith("#endif"):
+                depth -= 1
+            elif depth == 0 and re.search(r"\babl_?\b", line.split("//")[0]):
+                out.append(line)
+        assert not out, (src, out[:3])

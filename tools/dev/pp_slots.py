@@ -1,6 +1,6 @@
 """Development: slot timing of the ping-pong attention kernel (ablation build, bit 16 of the ablation word): shader cycles per
-tile of [V work | barrier wait | M work | barrier wait] per wave group.  Needs libaid_abl.so (all objects with -DAID_ABLATIONS):
-AID_LIB_PATH=.../libaid_abl.so python tools/dev/pp_slots.py"""
+tile of [V work | barrier wait | M work | barrier wait] per wave group.  Needs the development build (make -C tools/dev):
+AID_LIB_PATH=tools/dev/libaid_abl.so python tools/dev/pp_slots.py"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
