@@ -70,15 +70,18 @@ def extract_uniform_points(ds: Sequence[float], interpolation_size: int) -> List
 # ---- smoothest path through the explored frames (prior.py:212-297) ----------------------------------------------------------
 # Task: among the increasing node sequences 0 = p_0 < ... < p_{n-1} = m - 1 pick one whose edge weights w[p_k][p_{k+1}] fit
 # into the narrowest window.  The reference bisects the window width D to 1e-6 and, per trial D, slides a window
-# [w_min, w_min + D] over the sorted distinct weights, running a greedy label DP per window.  Formulation here:
-#   1. the EXACT threshold D* = min over windows of distinct weights [W[lo], W[hi]] that admit an n-node path, by two pointers
-#      over W (feasibility is monotone in both ends) with a boolean reachability product per check;
-#   2. the width the reference's bisection ENDS on is a function of D* alone (its predicate is  D >= D*), so the scalar
-#      iteration is replayed on that predicate without any path search;
-#   3. one label pass in the first window that fits that width, level-synchronous and vectorised over the predecessors, with
-#      parent pointers instead of stored paths.  Labels and tie-breaks are the reference's (keep, per (node, length), the
-#      partial path of smallest spread; among equals the smallest predecessor index), so the picked path is identical —
-#      pinned by tests/golden/prior_goldens.npz.
+# [w_min, w_min + D] over the sorted distinct weights — ONLY windows that end inside the weight range (it stops at the first
+# w_min + D > W[-1], prior.py:258-259) — running a greedy label DP per window.  That predicate is NOT "D >= the exact
+# threshold": a window that needs the largest weight is feasible only when some distinct weight sits exactly D below W[-1] or
+# lower, ties and small graphs make it non-monotone, and the reference returns None for about a quarter of small random graphs
+# (tests/golden/prior_goldens.npz `path*` pins 232 randomised cases, 60 of them None).  Formulation here:
+#   1. the reference's scalar bisection, trial by trial, on its real predicate — "some window [w, w + D], w a distinct weight,
+#      w + D <= W[-1], carries an n-node path" — where a window's test is a boolean reachability product (inside a window of
+#      width D every path's spread is <= D, so the reference's label DP succeeds exactly when a path exists);
+#   2. one label pass in the first feasible window of the last feasible trial, level-synchronous and vectorised over the
+#      predecessors, with parent pointers instead of stored paths.  Labels and tie-breaks are the reference's (keep, per
+#      (node, length), the partial path of smallest spread; among equals the smallest predecessor index), so the picked path
+#      is identical.
 def _edges_in(weights: np.ndarray, lo: float, hi: float) -> np.ndarray:
     """Upper-triangular mask of the existing edges whose weight lies in [lo, hi]."""
     m = weights.shape[0]
@@ -96,19 +99,14 @@ def _reachable(mask: np.ndarray, n: int) -> bool:
     return bool(front[-1])
 
 
-def _exact_spread(n: int, weights: np.ndarray, W: np.ndarray) -> Optional[float]:
-    """D*: the smallest W[hi] - W[lo] such that the edges with weights in [W[lo], W[hi]] carry an n-node path."""
-    best, hi = None, 0
-    for lo in range(len(W)):
-        hi = max(hi, lo)
-        while hi < len(W) and not _reachable(_edges_in(weights, W[lo], W[hi]), n):
-            hi += 1
-        if hi == len(W):
-            break                          # no window starting at or after W[lo] works any more
-        width = float(W[hi] - W[lo])
-        if best is None or width < best:
-            best = width
-    return best
+def _first_window(D: float, n: int, weights: np.ndarray, W: np.ndarray) -> Optional[float]:
+    """Lower end of the first window the reference's scan accepts for trial width D (prior.py:256-295), or None."""
+    for w_lo in W:
+        if w_lo + D > W[-1]:
+            break                                    # the reference never tries a window that ends beyond the largest weight
+        if _reachable(_edges_in(weights, w_lo, w_lo + D), n):
+            return float(w_lo)
+    return None
 
 
 def _label_pass(n: int, weights: np.ndarray, mask: np.ndarray, width: float) -> Optional[List[int]]:
@@ -145,30 +143,24 @@ def _label_pass(n: int, weights: np.ndarray, mask: np.ndarray, width: float) -> 
 
 
 def find_minimal_spread_and_path(n: int, m: int, weights) -> Tuple[Optional[float], Optional[List[int]]]:
-    """(window width, node path) of the smoothest n-node path 0 -> m - 1 through the explored frames; the path the
-    reference's bisection + window scan returns (prior.py:223-297), found as described above."""
+    """(window width, node path) of the smoothest n-node path 0 -> m - 1 through the explored frames — what the reference's
+    bisection + window scan returns (prior.py:223-297), including ``(None, None)`` where the reference finds nothing."""
     weights = np.asarray(weights, dtype=np.float64)
     iu = np.triu_indices(m, 1)
     present = weights[iu]
     W = np.unique(present[present != -1])
-    d_star = _exact_spread(n, weights, W)
-    # the reference's scalar bisection, replayed on its predicate "a window of width D admits a path" == (D >= D*)
-    low, high, width = 0.0, float(W[-1] - W[0]), None
+    low, high = 0.0, float(W[-1] - W[0])
+    width, start = None, None
     while high - low > 1e-6:
         D = (low + high) / 2
-        if d_star is not None and D >= d_star:
-            high, width = D, D
+        w_lo = _first_window(D, n, weights, W)
+        if w_lo is not None:
+            high, width, start = D, D, w_lo
         else:
             low = D
     if width is None:
         return None, None
-    for w_lo in W:                                   # first window of that width (it must end inside the weight range)
-        if w_lo + width > W[-1]:
-            break
-        path = _label_pass(n, weights, _edges_in(weights, w_lo, w_lo + width), width)
-        if path is not None:
-            return width, path
-    return None, None
+    return width, _label_pass(n, weights, _edges_in(weights, start, start + width), width)
 
 
 def extract_uniform_points_plus(features: Sequence[torch.Tensor], interpolation_size: int,

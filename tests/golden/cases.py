@@ -189,3 +189,39 @@ PRIOR_RUNS = [dict(exploration_size=8, init_alpha=3, init_beta=3, uniform=False)
 PRIOR_FITS = [([0.0, 0.5, 1.0], [0.2, 0.5]), ([0.0, 0.3, 0.5, 0.8, 1.0], [0.1, 0.25, 0.3, 0.05]),
               ([0.0, 0.2, 0.35, 0.5, 0.7, 0.9, 1.0], [0.05, 0.07, 0.2, 0.3, 0.1, 0.02])]
 PRIOR_UNIFORM = [([0.1, 0.2, 0.05, 0.3, 0.15, 0.2, 0.1, 0.05], 5), ([0.5, 0.1, 0.1, 0.1, 0.1, 0.1], 3), ([0.2] * 15, 7)]
+
+
+# ---- smoothest-path search (prior.py:223-297): randomised weight matrices, regenerated from seeds -------------------------------------
+# kinds: "metric" = distances of random points on a curve (what the exploration produces), "uniform" = i.i.d. weights, "quant" = weights
+# on a coarse grid (ties; windows that touch the largest weight), "missing" = uniform with some edges absent (-1).  ADVICE r3: the
+# reference's feasibility test skips every window with w_min + D > W[-1], so it is NOT the monotone predicate D >= D*.
+def prior_path_cases():
+    out = []
+    rs = np.random.RandomState(20240928)
+    for kind in ("metric", "uniform", "quant", "missing"):
+        for m in (3, 4, 5, 6, 8, 11, 14):
+            for rep in range(10 if m <= 8 else 4):
+                n = int(rs.randint(2, m + 1))
+                out.append((kind, m, n, int(rs.randint(0, 2 ** 31 - 1))))
+    return out
+
+
+def prior_path_weights(kind, m, seed):
+    rs = np.random.RandomState(seed)
+    w = np.full((m, m), -1.0)
+    iu = np.triu_indices(m, 1)
+    if kind == "metric":
+        t = np.sort(rs.rand(m))
+        pts = np.stack([np.cos(3 * t), np.sin(2 * t), t * t], axis=1) + 0.05 * rs.randn(m, 3)
+        d = np.linalg.norm(pts[:, None] - pts[None], axis=-1)
+        w[iu] = d[iu]
+    elif kind == "uniform":
+        w[iu] = rs.rand(len(iu[0]))
+    elif kind == "quant":
+        w[iu] = rs.randint(0, 5, size=len(iu[0])) / 4.0
+    else:
+        vals = rs.rand(len(iu[0]))
+        vals[rs.rand(len(iu[0])) < 0.25] = -1.0
+        w[iu] = vals
+        w[np.arange(m - 1), np.arange(1, m)] = rs.rand(m - 1)      # the chain 0 -> 1 -> ... -> m - 1 always exists
+    return w

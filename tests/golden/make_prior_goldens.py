@@ -46,9 +46,19 @@ def main():
         out[f"fit{i}"] = np.array(self._update_alpha_beta(list(xs), list(ds)), dtype=np.float64)
     for i, (ds, n) in enumerate(C.PRIOR_UNIFORM):
         out[f"uniform{i}"] = np.array(self.extract_uniform_points(list(ds), n))
-    np.savez(os.path.join(HERE, "prior_goldens.npz"), **out)
+    # randomised smoothest-path searches by the reference's own find_minimal_spread_and_path (width NaN / empty path = None)
+    import contextlib, io
+    for i, (kind, m, n, seed) in enumerate(C.prior_path_cases()):
+        w = C.prior_path_weights(kind, m, seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            d, path = self.find_minimal_spread_and_path(n, m, [list(map(float, row)) for row in w])
+        out[f"path{i}_d"] = np.array(np.nan if d is None else d, dtype=np.float64)
+        out[f"path{i}_p"] = np.array([] if path is None else path, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "prior_goldens.npz"), **out)
     for k, v in out.items():
-        print(k, v)
+        if not k.startswith("path"):
+            print(k, v)
+    print(sum(1 for k in out if k.endswith("_p")), "path cases,", sum(1 for k, v in out.items() if k.endswith("_p") and v.size == 0), "without a path")
 
 
 if __name__ == "__main__":

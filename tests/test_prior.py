@@ -124,3 +124,22 @@ def test_get_feature_goes_through_the_image_processor_like_the_reference():
     bp._get_feature(frame_u8.astype(np.float32) / 255.0)            # float frames in [0, 1] are not rescaled again
     assert seen["kw"] == ("pt", False)
     np.testing.assert_allclose(bp._get_feature(frame_u8.astype(np.float32) / 255.0).detach().numpy(), f.detach().numpy(), rtol=1e-6)
+
+
+def test_smoothest_path_search_equals_the_reference_on_random_graphs():
+    """232 randomised weight matrices (metric-like, i.i.d., tied / quantised, with missing edges; m = 3 .. 14, n = 2 .. m)
+    through the reference's own find_minimal_spread_and_path (make_prior_goldens.py): same width bit for bit, same path, and
+    ``(None, None)`` exactly where the reference returns it (its window scan skips every window that ends past the largest weight)."""
+    cases = C.prior_path_cases()
+    assert len(cases) == 232
+    none = 0
+    for i, (kind, m, n, seed) in enumerate(cases):
+        d, path = P.find_minimal_spread_and_path(n, m, C.prior_path_weights(kind, m, seed))
+        gd, gp = float(G[f"path{i}_d"]), G[f"path{i}_p"].tolist()
+        if not gp:
+            assert d is None and path is None and np.isnan(gd), (kind, m, n, seed)
+            none += 1
+        else:
+            assert path == gp and d == gd, (kind, m, n, seed, path, gp)
+            assert path[0] == 0 and path[-1] == m - 1 and len(path) == n and path == sorted(set(path))
+    assert none == 60
