@@ -15,7 +15,7 @@ from .interp import generate_beta_tensor, linear_interpolation, slerp, spherical
 from .processors import (HipAttnProcessor, HipIPAdapterAttnProcessor, InnerInterpolatedAttnProcessor,
                          InnerInterpolatedIPAttnProcessor, InterpolatedAttnProcessor, OuterInterpolatedAttnProcessor,
                          OuterInterpolatedIPAttnProcessor, ScaleControlIPAttnProcessor, activate_aid,
-                         deactivate_aid, load_aid, load_aid_ip_adapter)
+                         clear_text_kv_cache, clear_weight_caches, deactivate_aid, load_aid, load_aid_ip_adapter)
 from .attn_shim import AttnShim, AttnStackUNet, IPAdapterShim
 from . import ops, _lib, sequence, loop, dist, prior, pipelines
 from .prior import BetaPriorExplorer, BetaPriorPipeline
@@ -27,6 +27,7 @@ __all__ = [
     "InterpolatedAttnProcessor", "OuterInterpolatedAttnProcessor", "InnerInterpolatedAttnProcessor",
     "OuterInterpolatedIPAttnProcessor", "InnerInterpolatedIPAttnProcessor", "ScaleControlIPAttnProcessor",
     "HipAttnProcessor", "HipIPAdapterAttnProcessor", "load_aid", "load_aid_ip_adapter", "activate_aid", "deactivate_aid",
+    "clear_text_kv_cache", "clear_weight_caches",
     "AttnShim", "AttnStackUNet", "IPAdapterShim", "ops",
     "BetaPriorPipeline", "BetaPriorExplorer", "InterpolationStableDiffusionPipeline", "InterpolationStableDiffusionXLPipeline", "DDIMSchedulerLite", "StackDenoiser",
 ]

@@ -142,8 +142,10 @@ class AttnStackUNet(nn.Module):
     """
 
     def __init__(self, model: str = "sd15", dtype=torch.float16, device=None, seed: int = 1002,
-                 scale_down: int = 1, channel_div: int = 1):
-        """``scale_down`` divides every S, ``channel_div`` every width (structure-only uses in tests)."""
+                 scale_down: int = 1, channel_div: int = 1, head_div: int = 1):
+        """``scale_down`` divides every S, ``channel_div`` every width (structure-only uses in tests), ``head_div`` the number of
+        heads AND the width together — the head dims of the real layers (40 / 80 / 160, 64) are kept, so the shipped attention
+        kernels run; used by the 50-step end-to-end parity tests, whose fp64 oracle loop is bound by the weight bytes."""
         super().__init__()
         spec = MODEL_SPECS[model]
         self.model = model
@@ -153,6 +155,9 @@ class AttnStackUNet(nn.Module):
         for loc, nblk, s, c, h in spec["layers"]:
             s = max(s // scale_down, 1)
             c = c // channel_div
+            if head_div > 1:
+                assert h % head_div == 0, (model, h, head_div)
+                c, h = c // head_div, h // head_div
             for b in range(nblk):
                 for which, cd in (("attn1", None), ("attn2", self.cross_dim)):
                     names.append(f"{loc}.attentions.{b}.transformer_blocks.0.{which}.processor")

@@ -586,11 +586,17 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 
 // May the ping-pong kernel run the single-segment frames of this call?  d = 64, whole 64-key tiles, at least two of them.
 bool attn_pp_supported(const AidAttnArgs& a) {
-    const int64_t kb = (int64_t)a.n_kv * a.k_fs * 2, vb = (int64_t)a.n_kv * a.vt_fs * 2;    // segment rows ride in 32-bit scalar offsets
+    // segment rows, heads and the next item's Q rows ride in 32-bit offsets of descriptors with num_records 0x7fffffff: every tensor
+    // the kernel reads through one stays below 2 GB (k / vt hold n_kv rows, k2 / vt2 and q one row per FRAME)
+    const int64_t lim = 1ll << 31;
+    const int64_t kb = (int64_t)a.n_kv * a.k_fs * 2, vb = (int64_t)a.n_kv * a.vt_fs * 2;
+    const int64_t k2b = a.mode == AID_MODE_INNER ? (int64_t)a.n_frames * a.k_fs * 2 : 0;
+    const int64_t v2b = a.mode == AID_MODE_INNER ? (int64_t)a.n_frames * a.vt_fs * 2 : 0;
+    const int64_t qb = (int64_t)a.n_frames * a.q_fs * 2;
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.k2) |
                          reinterpret_cast<uintptr_t>(a.vt2);                               // LDS-DMA moves 16-byte pieces
     return a.d == 64 && a.l % PKT == 0 && a.l >= 2 * PKT && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.k_fs % 8 == 0 && a.vt_fs % 8 == 0 &&
-           (al & 15) == 0 && kb < (1ll << 31) && vb < (1ll << 31);
+           (al & 15) == 0 && kb < lim && vb < lim && k2b < lim && v2b < lim && qb < lim;
 }
 
 hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) {

@@ -23,7 +23,7 @@ from typing import Callable, Dict, Optional, Sequence
 import torch
 
 from .processors import (HipAttnProcessor, InnerInterpolatedAttnProcessor, InterpolatedAttnProcessor,
-                         OuterInterpolatedAttnProcessor)
+                         OuterInterpolatedAttnProcessor, clear_weight_caches)
 
 EARLY_MODES = ("pure_inner", "fused_inner", "pure_outer", "fused_outer")
 
@@ -40,6 +40,7 @@ def install_sequence_processors(unet, size: int, early: str = "fused_outer", alp
     alpha = num_inference_steps if alpha is None else alpha
     beta = num_inference_steps if beta is None else beta
     cls = OuterInterpolatedAttnProcessor if early.endswith("outer") else InnerInterpolatedAttnProcessor
+    clear_weight_caches()                    # (see processors.py: in-place weight edits are invisible to the cache keys)
     procs = {}
     for name in unet.attn_processors.keys():
         p = cls(size=size, is_fused=early.startswith("fused"), alpha=alpha, beta=beta,

@@ -95,9 +95,9 @@ class StackDenoiser(nn.Module):
     "steps" = torch LayerNorm / processor call / torch add."""
 
     def __init__(self, model: str = "sd15", dtype=torch.float16, device=None, seed: int = 1002, scale_down: int = 16,
-                 latent_hw: Tuple[int, int] = (16, 16), sublayers: str = "fused"):
+                 latent_hw: Tuple[int, int] = (16, 16), sublayers: str = "fused", head_div: int = 1):
         super().__init__()
-        self.stack = AttnStackUNet(model, dtype=dtype, device=device, seed=seed, scale_down=scale_down)
+        self.stack = AttnStackUNet(model, dtype=dtype, device=device, seed=seed, scale_down=scale_down, head_div=head_div)
         self.stack.sublayers = sublayers
         self.latent_hw = latent_hw
         self.in_channels = 4
@@ -161,29 +161,49 @@ class _PassGraphs:
     plain, unconditional (or the two batched variants) — each launching a few hundred kernels per call.  The first call of
     a kind runs once eagerly (lazy kernel attributes, coefficient buffers, workspaces, the text K / V cache), is captured, and
     every later step only copies the step's inputs (scaled latents, timestep) into the captured buffers and replays.
-    ``activate_aid(it)`` rewrites the coefficient buffers in place, so a replay reads the live schedule."""
+    ``activate_aid(it)`` rewrites the coefficient buffers in place, so a replay reads the live schedule.
+
+    What a replay FREEZES: every Python-side decision of the first call of a pass kind — the frame -> context map
+    (``ctx_index``), ``plain_tail``, the IP-Adapter scales, which processor object sits on which layer.  A
+    ``callback_on_step_end`` that swaps processors or embeddings between steps has no effect on replayed passes: run such loops
+    with ``use_graphs=False``.  Each pass kind also holds a private pool with one UNet pass of activations.
+
+    A UNet whose forward cannot be captured (a host synchronisation or a host -> device copy inside it) does not abort the
+    run: the failed capture is abandoned, graphs are switched off for the rest of the run (``self.enabled = False``,
+    ``self.fallback_reason`` says why) and the pass runs eagerly."""
 
     def __init__(self, enabled: bool):
         self.enabled = bool(enabled)
+        self.fallback_reason: Optional[str] = None
         self._ent: Dict[Any, Tuple] = {}
+
+    def _capture(self, fn: Callable, inputs: Dict[str, torch.Tensor]):
+        static = {k: v.clone() for k, v in inputs.items()}
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            fn(**static)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = fn(**static)
+        return graph, static, out
 
     def run(self, key, fn: Callable, **inputs: torch.Tensor):
         if not self.enabled:
             return fn(**inputs)
         ent = self._ent.get(key)
         if ent is None:
-            static = {k: v.clone() for k, v in inputs.items()}
-            cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                fn(**static)
-            cur.wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = fn(**static)
-            ent = (graph, static, out)
+            try:
+                ent = self._capture(fn, inputs)
+            except Exception as e:              # noqa: BLE001 — anything a foreign UNet does that a stream capture forbids
+                self.enabled = False
+                self.fallback_reason = f"{type(e).__name__}: {e}"
+                self._ent.clear()
+                torch.cuda.synchronize()
+                return fn(**inputs)
             self._ent[key] = ent
         graph, static, out = ent
         for k, v in inputs.items():
@@ -364,6 +384,7 @@ class InterpolationStableDiffusionPipeline:
         lat = batch.latents
         cond, unc = batch.cond.to(dev, dtype), batch.uncond.to(dev, dtype)
         graphs = _PassGraphs(_use_graphs(use_graphs, dev))
+        P.clear_weight_caches()              # caches derived from weights live for ONE run (in-place weight edits are invisible to their keys)
 
         # loop-invariant conditioning, moved to the device once (the reference rebuilds the dict every step, :1850-1867)
         added_c = self._added_cond(None if pooled is None else pooled[0], 3, None if img is None else img[0])

@@ -289,8 +289,27 @@ def _ln_folded(attn, norm, cross: bool):
 # address can never hit.  Tensors whose version counter cannot be read (inference mode) are not cached.
 # Captured hipGraphs hold the cached buffers' addresses: they stay valid as long as the context tensor they were captured
 # with is alive; re-capture after replacing weights.  ``TEXT_KV_CACHE = False`` switches the cache off.
+#
+# What the keys CANNOT see: an edit through ``.data`` (``w.data += delta`` — peft's LoRA ``merge`` — or ``w.data.copy_()``)
+# changes neither the address nor ``_version``.  Therefore the caches are scoped to a RUN: ``clear_weight_caches()`` is called by
+# ``load_aid`` / ``load_aid_ip_adapter`` / ``install_sequence_processors`` and at the start of every ``interpolate`` /
+# ``interpolate_single``; a caller that edits weights in place BETWEEN processor calls of its own loop must call it too
+# (INTEGRATION.md §3).
 TEXT_KV_CACHE = True
 _KV_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def clear_text_kv_cache() -> None:
+    """Drop every cached text key / value projection (they are re-projected by the next cross-attention call)."""
+    _KV_CACHE.clear()
+
+
+def clear_weight_caches() -> None:
+    """Drop everything derived from attention WEIGHTS: the text K / V cache and the folded LayerNorm weights.  Call after an
+    in-place weight edit that leaves ``data_ptr`` and ``_version`` unchanged (``w.data += ...``, a merged LoRA); graphs captured
+    before the call still read the old derived tensors and must be re-captured."""
+    _KV_CACHE.clear()
+    _FOLD_CACHE.clear()
 
 
 def _vkey(t: torch.Tensor):
@@ -366,15 +385,31 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
                                "end-point frames)")
         # local frames keep their (possibly shared) context rows; the two end-point contexts are appended behind them
         base = [int(i) for i in ctx_index] if ctx_index is not None else list(range(n))
-        if ctx_index is not None and ctx.shape[0] == n and max(base) + 1 != n:
-            ctx = ctx.index_select(0, torch.tensor([base.index(r) for r in range(max(base) + 1)], device=ctx.device))
         nctx = max(base) + 1
-        if ctx.shape[0] != nctx:
-            raise RuntimeError(f"encoder_hidden_states has {ctx.shape[0]} rows; the frame -> context map needs {nctx}")
-        ctx = torch.cat([ctx, proc.endpoint_ctx.to(ctx.dtype)], dim=0).contiguous()
-        ctx, ctx_map, _ = _shared_context(proc._ctx_cache, base + [nctx, nctx + 1], ctx, n + 2)
-        y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode=mode, fused=proc.is_fused, coef=coef,
-                              begin=nctx, end=nctx + 1, ctx_map=ctx_map[:n], n_plain=proc.plain_tail)
+        if len(base) != n or min(base) < 0 or sorted(set(base)) != list(range(nctx)):
+            raise RuntimeError("ctx_index must have one entry per local frame and use every context row 0 .. n_distinct-1")
+        # the concatenated tensor [distinct local contexts ; two end-point contexts] is loop-invariant: built ONCE per
+        # (caller's context tensor, map) — no per-call host -> device copy in front of the side-stream exchange —
+        # and it is the tensor the text K / V cache keys on
+        ck = ("exchange", tuple(base), ctx.data_ptr(), _version_of(ctx), tuple(ctx.shape), proc.endpoint_ctx.data_ptr(),
+              _version_of(proc.endpoint_ctx))
+        hit = proc._ctx_cache.get(ck)
+        if hit is None:
+            own = ctx
+            if own.shape[0] == n and nctx != n:
+                own = own.index_select(0, torch.tensor([base.index(r) for r in range(nctx)], device=ctx.device))
+            elif own.shape[0] != nctx:
+                raise RuntimeError(f"encoder_hidden_states has {ctx.shape[0]} rows; the frame -> context map needs {nctx}")
+            for old_key in [k_ for k_ in proc._ctx_cache if k_ and k_[0] == "exchange"]:
+                proc._ctx_cache.pop(old_key, None)                # one live entry per processor (per run)
+            hit = (torch.cat([own, proc.endpoint_ctx.to(ctx.dtype)], dim=0).contiguous(), weakref.ref(ctx))
+            proc._ctx_cache[ck] = hit
+        full = hit[0]
+        full_map = base + [nctx, nctx + 1]
+        ctx2, ctx_map, idx2 = _shared_context(proc._ctx_cache, full_map, full, n + 2)
+        y = ops.processor_fwd(x, ctx2, wq, wk, wv, wo, bo, attn.heads, mode=mode, fused=proc.is_fused, coef=coef,
+                              begin=nctx, end=nctx + 1, ctx_map=ctx_map[:n], n_plain=proc.plain_tail,
+                              kv_cached=_text_kv(attn, full, ctx2, idx2, wk, wv))
         return _epilogue(attn, y, residual, shape4)
     if ctx is not None and ctx_index is not None:
         ctx, ctx_map, idx = _shared_context(proc._ctx_cache, ctx_index, ctx, x.shape[0])
@@ -688,6 +723,7 @@ def load_aid(unet, t: Optional[float] = 0.5, is_fused: bool = True, atype: str =
     (pipeline_interpolated_sd.py:950-970).  ``keep_original=True`` keeps the processor that was
     installed before as ``original_attn`` exactly like the reference; the default routes the
     de-activated passes through the HIP plain-attention kernel instead."""
+    clear_weight_caches()                    # a (re-)installation is the boundary after which weights may have been edited
     procs = {}
     current = unet.attn_processors
     for name in current.keys():
@@ -719,6 +755,7 @@ def load_aid_ip_adapter(unet, t: Optional[float] = 0.5, is_fused: bool = True, e
                "scale_control": ScaleControlIPAttnProcessor}
     if early not in classes:
         raise ValueError(f"early must be one of {sorted(classes)}, got {early!r}")
+    clear_weight_caches()
     procs = {}
     current = unet.attn_processors
     for name, cur in current.items():
