@@ -108,7 +108,14 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension has not been built "
             f"(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC_DIR}`). "
             "This package has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    _lib = bind(LIB_PATH)
+    return _lib
+
+
+def bind(path: str) -> C.CDLL:
+    """dlopen one build of the library and declare the prototypes of include/aid_hip.h (development tools load several builds
+    side by side, tools/dev/pp_variants.py)."""
+    lib = C.CDLL(path)
     lib.aid_abi_version.restype = C.c_int
     lib.aid_strerror.restype = C.c_char_p
     lib.aid_strerror.argtypes = [C.c_int]
@@ -144,7 +151,6 @@ def load() -> C.CDLL:
     lib.aid_profile_end.argtypes = [C.POINTER(AidProfileEntry), C.c_int]
     if lib.aid_abi_version() != AID_ABI_VERSION:
         raise RuntimeError(f"libaid_hip.so ABI version {lib.aid_abi_version()} != expected {AID_ABI_VERSION}; rebuild")
-    _lib = lib
     return lib
 
 

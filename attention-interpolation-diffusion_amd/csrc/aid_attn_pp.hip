@@ -28,6 +28,20 @@
 #include "aid_common.hpp"
 #include "aid_kernels.hpp"
 
+// development switches of this file (tools/dev/pp_variants.py builds one library per setting; the defaults are the shipped kernel)
+#ifndef PP_CHAINS
+#define PP_CHAINS 1                     // independent partial row sums / maximum chains in the V slot (1 = one serial chain each)
+#endif
+#ifndef PP_ALWAYS_DMA
+#define PP_ALWAYS_DMA 0                 // 1: the DMA stream never stops (behind the last item it wraps into valid memory): no tail branches in the V slot
+#endif
+#ifndef PP_SPEC
+#define PP_SPEC 0                       // 1 (PLAIN / INNER instantiations): the maximum chains and half of the exponentials ride in the M slot's PV half
+#endif
+#ifndef PP_PRIO
+#define PP_PRIO 0                       // 1: static s_setprio 1 for the second wave group (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
+
 namespace aid {
 
 namespace {
@@ -78,7 +92,9 @@ __device__ __forceinline__ void slot_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T>
+// MODE = the call's mode (AID_MODE_*): a PLAIN instantiation carries none of the segment machinery, an INNER one no parked state — the
+// registers that frees (34 + the scalar item records) pay for the speculative exponentials in the M slot (PP_SPEC)
+template <typename T, int MODE>
 __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) {
     typedef typename Vec<T>::v8 T8;
     typedef typename Vec<T>::v4 T4;
@@ -138,7 +154,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         const int kvf = a.kv_map ? a.kv_map[N_fr] : N_fr;
         int seg0 = kvf, seg1 = 0;
         N_nseg = 1; N_t2 = 0; N_park = -1; N_swap = -1; N_wb = 0.f; N_we = 1.f; N_skip = false;
-        if (a.mode != AID_MODE_PLAIN) {
+        if (MODE != AID_MODE_PLAIN) {
             const float cf = a.coef[N_fr];
             const bool single = cf < 0.f || (a.fused && ((cf == 0.f && kvf == row_b) || (cf == 1.f && kvf == row_e)));
             if (!single) {
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 const bool both = cf != 0.f && cf != 1.f;
                 const int side = row_b + (cf == 1.f ? 1 : 0) * (row_e - row_b);       // the end-point row of a one-sided frame
                 const int fz = a.fused ? 1 : 0;
-                if (a.mode == AID_MODE_OUTER) {
+                if (MODE == AID_MODE_OUTER) {
                     N_nseg = fz + (both ? 2 : 1);
                     const int first = both ? row_b : side;
                     seg0 = fz * kvf + (1 - fz) * first;
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const int kstep = PKT * a.ldk * 2;
     auto dma_next = [&](int st) __attribute__((always_inline)) {    // st: ring stage, a constant wherever the caller's tile index is
         char* dst = smem + st * PTILE + wave * 1024;
-        if (d2) {                                               // (a branch, not a select between the two descriptors)
+        if (MODE == AID_MODE_INNER && d2) {                     // (a branch, not a select between the two descriptors)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rk2, (__attribute__((address_space(3))) void*)dst, 16, kvo, dk, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rv2, (__attribute__((address_space(3))) void*)(dst + PNS * PTILE), 16, vvo, dv, 0, 0);
         } else {
@@ -272,13 +288,34 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     float m = 0.f;
     bool fresh = true;
     f32x16 o[2], sc[2];
-    float lsum = 0.f;                   // row sum of the ROUNDED P over the 32 keys per tile this lane holds (the partner lane has the others)
+    // row sum of the ROUNDED P over the 32 keys per tile this lane holds (the partner lane has the others), as NL independent
+    // partial sums: 16 v_dot2c in a row on ONE accumulator are a serial dependency chain (the dependent-issue latency, not the
+    // issue rate, then sets the pace of that part of the V slot)
+    constexpr int NL = PP_CHAINS;
+    float lsum[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) lsum[i] = 0.f;
+    auto lsum_total = [&]() __attribute__((always_inline)) {
+        float t = lsum[0];
+#pragma unroll
+        for (int i = 1; i < NL; ++i) t += lsum[i];
+        return t;
+    };
+    auto lsum_set = [&](float v) __attribute__((always_inline)) {
+        lsum[0] = v;
+#pragma unroll
+        for (int i = 1; i < NL; ++i) lsum[i] = 0.f;
+    };
     T8 pf[4];
     f32x16 cneg;                        // -m as an accumulator block (C operand of a tile's first score MFMAs), rebuilt when m moves
     f32x16 po[2];                       // parked: O of the own-keys state while the begin side runs, then the finished begin side
     float pl = 0.f, pm = 0.f;           // parked row sum (this lane's register of the row-sum block) and row reference
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; po[0][r] = 0.f; po[1][r] = 0.f; cneg[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; cneg[r] = 0.f; }
+    if (MODE == AID_MODE_OUTER) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { po[0][r] = 0.f; po[1][r] = 0.f; }
+    }
     asm volatile("" : "+v"(cneg));
 #pragma unroll
     for (int i = 0; i < 4; ++i) pf[i] = zero8<T>();
@@ -304,6 +341,28 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 
     // operand fragments: kf = K(t + 1) for S(t + 1), vf = V^T(t) for O += V^T(t) P(t)^T, all four k-steps each
     T8 kf[4][2], vf[4][2];
+    // PP_SPEC: VALU work of tile t + 1 that rides between the PV MFMAs of M(t + 1), behind the score MFMAs that produced S(t + 1) — a
+    // wave alone in its V slot issues one VALU instruction per 5 - 6.5 cycles (11.4 for v_exp_f32) whatever the port could take, while
+    // the M-slot wave has ~6 idle issue slots per MFMA: four maximum chains over 8 scores each (xc) and the exponentials of the first
+    // 16 scores (pe), SPECULATIVE — formed against the current row reference; the V slot takes the rare slow path on xc and then
+    // recomputes them from the shifted scores, which stay intact in `sc`.
+    constexpr bool SPEC = PP_SPEC && MODE != AID_MODE_OUTER;
+    constexpr int NPE = PP_SPEC >= 2 ? 32 : 16;                 // speculative exponentials per tile (PP_SPEC = 2: all of them)
+    float xc[4], pe[NPE];
+    auto sflat = [&](int i) __attribute__((always_inline)) -> float { return sc[i >> 4][i & 15]; };
+    auto chain_links = [&](int c, int half) __attribute__((always_inline)) {       // two links of chain c (flat scores 8 c .. 8 c + 7)
+        const int b = 8 * c + 4 * half;
+        if (half == 0) xc[c] = fmaxf(fmaxf(sflat(b), sflat(b + 1)), fmaxf(sflat(b + 2), sflat(b + 3)));
+        else           xc[c] = fmaxf(fmaxf(xc[c], sflat(b)), fmaxf(fmaxf(sflat(b + 1), sflat(b + 2)), sflat(b + 3)));
+    };
+    auto spec_unit = [&](int u) __attribute__((always_inline)) {                   // unit u of 8: two chain links + NPE / 8 exponentials
+        chain_links(u >> 1, u & 1);
+#pragma unroll
+        for (int e = 0; e < NPE / 8; ++e) {
+            const int j = u * (NPE / 8) + e;
+            pe[j] = __builtin_amdgcn_exp2f(sc[j >> 4][j & 15]);
+        }
+    };
     auto lds_k = [&](int st, int ks, int b) __attribute__((always_inline)) {           // st: ring stage, a constant wherever it matters
         return *reinterpret_cast<const T8*>(smem + kad[ks] + (st * PTILE + b * 4096));
     };
@@ -338,6 +397,11 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             pin();
             kf[kk][w] = lds_k(sk, kk, w);                       // (kf[kk][w] was released by score MFMA 2 kk + w, eight or more MFMAs ago)
             pin();
+            if (SPEC && i >= 1) {                               // (the gap behind PV MFMA 0 is too close to the last score MFMA: hipcc pads it)
+                spec_unit(i - 1);
+                if (i == 7) spec_unit(7);
+                pin();
+            }
         }
     };
 
@@ -351,7 +415,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         else             wait_vm<0>();
     };
     auto vslot = [&](int t) __attribute__((always_inline)) {
-        const bool issue = has_next || t + LEAD < NT;
+        const bool issue = PP_ALWAYS_DMA || has_next || t + LEAD < NT;
 #ifdef AID_ABLATIONS
         if (p.abl & 1) {                                        // 1: no VALU work in the V slot
             if (!(p.abl & 2) && issue) dma_next((t + LEAD) & (PNS - 1));
@@ -365,12 +429,31 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             && !(p.abl & 2)
 #endif
         ) dma_next((t + LEAD) & (PNS - 1));
-        float xm = fmaxf(sc[0][0], sc[0][1]);
+        float xm;
+        if (SPEC) {
+            xm = fmaxf(fmaxf(xc[0], xc[1]), fmaxf(xc[2], xc[3]));
+        } else if (NL == 1) {
+            xm = fmaxf(sc[0][0], sc[0][1]);
 #ifdef AID_ABLATIONS
-        if (!(p.abl & 8))                                       // 8: no head-room check (the maximum chain)
+            if (!(p.abl & 8))                                   // 8: no head-room check (the maximum chain)
 #endif
 #pragma unroll
-        for (int i = 1; i < 16; ++i) xm = fmaxf(fmaxf(xm, sc[i >> 3][(2 * i) & 15]), sc[i >> 3][(2 * i + 1) & 15]);
+            for (int i = 1; i < 16; ++i) xm = fmaxf(fmaxf(xm, sc[i >> 3][(2 * i) & 15]), sc[i >> 3][(2 * i + 1) & 15]);
+        } else {                                                // NL independent chains over 32 / NL values each, then a short tree
+            float xc[NL];
+            constexpr int PER = 32 / NL;
+#pragma unroll
+            for (int c = 0; c < NL; ++c) {
+                const int b0 = c * PER;
+                xc[c] = fmaxf(sc[b0 >> 4][b0 & 15], sc[(b0 + 1) >> 4][(b0 + 1) & 15]);
+#pragma unroll
+                for (int i = 2; i < PER; i += 2)
+                    xc[c] = fmaxf(fmaxf(xc[c], sc[(b0 + i) >> 4][(b0 + i) & 15]), sc[(b0 + i + 1) >> 4][(b0 + i + 1) & 15]);
+            }
+            xm = xc[0];
+#pragma unroll
+            for (int c = 1; c < NL; ++c) xm = fmaxf(xm, xc[c]);
+        }
         if (fresh || __any(xm > XTH)) {
             // slow path (first tile of the row, or a score out-grew the head-room): move the reference to the row maximum,
             // rescale O (its ones row = l included) and shift this tile's arguments; PV(t - 1) is complete, O is at rest
@@ -383,12 +466,17 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             asm volatile("" : "+v"(cneg));                      // (opaque: keeps hipcc from rebuilding the block in every M slot)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-            lsum *= alpha;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) lsum[i] *= alpha;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[b][r] -= shift;
             fresh = false;
+            if (SPEC) {
+#pragma unroll
+                for (int r = 0; r < NPE; ++r) pe[r] = __builtin_amdgcn_exp2f(sc[r >> 4][r & 15]);
+            }
         }
         // lane (q, hi): sc[b][r] belongs to key 32 b + 16 (r >> 3) + 8 hi + (r & 7) of the tile = k-step 2 b + (r >> 3) of PV
 #pragma unroll
@@ -397,7 +485,8 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             for (int u = 0; u < 2; ++u) {
                 f32x8 pv;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
+                for (int e = 0; e < 8; ++e)
+                    pv[e] = (SPEC && 16 * b + 8 * u + e < NPE) ? pe[(16 * b + 8 * u + e) % NPE] : __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
                 pf[2 * b + u] = cvt8<T>(pv);
             }
         // row sums of the rounded P: v_dot2c against (1, 1), two keys per instruction (the matrix pipe's ones-row block cost 4 of 20 MFMAs)
@@ -405,7 +494,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         for (int i = 0; i < 4; ++i) {
             const u32x4 w4 = __builtin_bit_cast(u32x4, pf[i]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) lsum = dot2_ones<T>(w4[e], lsum);
+            for (int e = 0; e < 4; ++e) lsum[(4 * i + e) % NL] = dot2_ones<T>(w4[e], lsum[(4 * i + e) % NL]);
         }
         if (issue) wait_vm<6>();                                // steady state: the three tiles behind t + 3 stay in flight
         else       retire(NT - 4 - t);                          // (last item: the stream has run out)
@@ -416,11 +505,12 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     auto park = [&]() __attribute__((always_inline)) {          // own keys done: park the state, the begin side continues on it
 #pragma unroll
         for (int r = 0; r < 16; ++r) { po[0][r] = o[0][r]; po[1][r] = o[1][r]; }
-        pl = lsum;
+        pl = lsum_total();
         pm = m;
     };
     auto swap_sides = [&]() __attribute__((always_inline)) {    // begin side done: keep (1 - c) O_b / l_b, resume the own-keys state
-        const float lrow = lsum + other_half(lsum);             // (all lanes take part in the exchange)
+        const float lown = lsum_total();
+        const float lrow = lown + other_half(lown);             // (all lanes take part in the exchange)
         const float wb = w_b / lrow;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -430,7 +520,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 o[d][r] = po[d][r];
                 po[d][r] = rb;
             }
-        lsum = pl;
+        lsum_set(pl);
         const float back = m - pm;                              // S(t) was formed against the begin side's reference (>= the parked one)
         m = pm;
 #pragma unroll
@@ -455,7 +545,8 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             return;
         }
 #endif
-        const float inv = w_e / (lsum + other_half(lsum));      // (w_e = 1 unless this frame mixes two sides)
+        const float lfin = lsum_total();
+        const float inv = w_e / (lfin + other_half(lfin));      // (w_e = 1 unless this frame mixes two sides)
         const int q = q0 + l31;
         if (q < a.s) {
             const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
@@ -467,7 +558,11 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                     const int dv_ = 32 * d + 8 * g + 4 * hi;
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (o[d][4 * g + e] * inv + po[d][4 * g + e]) * osc;      // po: the begin side, or zero
+                    for (int e = 0; e < 4; ++e) {
+                        float r_ = o[d][4 * g + e] * inv;
+                        if (MODE == AID_MODE_OUTER) r_ += po[d][4 * g + e];      // the begin side, or zero
+                        v[e] = r_ * osc;
+                    }
                     if (a.accumulate) v += up4<T>(*reinterpret_cast<const T4*>(orow + dv_));
                     *reinterpret_cast<T4*>(orow + dv_) = cvt4<T>(v);
                 }
@@ -492,16 +587,20 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // ---- prologue: pieces of tiles 0 .. 5 requested, 0 .. 2 retired and published; S(0); fragments of K(1) ----------------
 #pragma unroll
     for (int t = 0; t < LEAD; ++t)
-        if (t < NT) dma_next(t);
+        if (PP_ALWAYS_DMA || t < NT) dma_next(t);
 #ifdef AID_ABLATIONS
     if (p.abl & 32) { tl[1] = clock64(); asm volatile("" :: "v"(qf[0]), "v"(qf[3])); }
 #endif
-    retire(NT - 3);
+    if (PP_ALWAYS_DMA) wait_vm<6>();
+    else               retire(NT - 3);
 #ifdef AID_ABLATIONS
     if (p.abl & 32) tl[2] = clock64();
 #endif
     slot_barrier();
     if (grp == 1) slot_barrier();                               // the second group runs one barrier behind
+#if PP_PRIO
+    if (grp == 1) __builtin_amdgcn_s_setprio(1);                // (grp comes from a readfirstlane: a scalar branch around one s_setprio)
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) kf[i >> 1][i & 1] = lds_k(0, i >> 1, i & 1);
     f32x16 zacc;
@@ -518,6 +617,12 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         for (int i = 0; i < 8; ++i) kf[i >> 1][i & 1] = lds_k(1, i >> 1, i & 1);      // nt >= 2
     }
     settle();
+    if (SPEC) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) chain_links(i >> 1, i & 1);
+#pragma unroll
+        for (int r = 0; r < NPE; ++r) pe[r] = 0.f;              // (tile 0 takes the slow path and recomputes them)
+    }
     slot_barrier();
 #ifdef AID_ABLATIONS
     if (p.abl & 32) tl[3] = clock64();
@@ -537,9 +642,11 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         // DMA and fragment read — is a compile-time constant in each copy (segments of a multi-segment frame, and every item of a
         // persistent launch, are whole trips).
 #pragma nounroll
-        for (int sgi = 0; sgi < nseg; ++sgi) {
-            if (sgi == park_at) park();
-            if (sgi == swap_at) swap_sides();
+        for (int sgi = 0; sgi < (MODE == AID_MODE_PLAIN ? 1 : nseg); ++sgi) {
+            if (MODE == AID_MODE_OUTER) {
+                if (sgi == park_at) park();
+                if (sgi == swap_at) swap_sides();
+            }
             const int t_end = (sgi + 1) * nt;
             for (int t8 = sgi * nt; t8 < t_end; t8 += 8) {
 #pragma unroll
@@ -571,14 +678,19 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         if (!has_next) break;
         // the next item: its S(0) is in `sc`; everything else starts over
         fresh = true;
-        lsum = 0.f;
+        lsum_set(0.f);
         pl = 0.f;
         pm = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; po[0][r] = 0.f; po[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+        if (MODE == AID_MODE_OUTER) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { po[0][r] = 0.f; po[1][r] = 0.f; }
+        }
         adopt();
         dseg = 0;                                               // the DMA stream is LEAD tiles into this item's first segment already
     }
+    if (PP_ALWAYS_DMA) wait_vm<0>();                            // (the wrapped requests behind the last item: nobody reads them)
     if (grp == 0) slot_barrier();                               // both groups pass the same number of barriers
 }
 
@@ -609,16 +721,22 @@ hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) 
     p.abl = tune(TUNE_ATTN_RES_CHUNKS) > 100 ? tune(TUNE_ATTN_RES_CHUNKS) - 100 : 0;
 #endif
     const size_t smem = (size_t)PNS * PSTAGE + 8 * 4096;        // ring + the next item's Q rows
-    static PerDevice<bool> attr_set[2];
+    static PerDevice<int> attr_set[2];
     const int ti = a.dtype == AID_DTYPE_F16 ? 0 : 1;
-    bool* done = attr_set[ti].slot();
+    int* done = attr_set[ti].slot();
     if (!done) return hipErrorInvalidDevice;
-    const void* fn = ti == 0 ? reinterpret_cast<const void*>(&aid_attn_pp_kernel<f16>)
-                             : reinterpret_cast<const void*>(&aid_attn_pp_kernel<bf16>);
-    if (!*done) {
+    if (a.mode < AID_MODE_PLAIN || a.mode > AID_MODE_OUTER) return hipErrorInvalidValue;
+    const void* fns[2][3] = {
+        {reinterpret_cast<const void*>(&aid_attn_pp_kernel<f16, AID_MODE_PLAIN>), reinterpret_cast<const void*>(&aid_attn_pp_kernel<f16, AID_MODE_INNER>),
+         reinterpret_cast<const void*>(&aid_attn_pp_kernel<f16, AID_MODE_OUTER>)},
+        {reinterpret_cast<const void*>(&aid_attn_pp_kernel<bf16, AID_MODE_PLAIN>), reinterpret_cast<const void*>(&aid_attn_pp_kernel<bf16, AID_MODE_INNER>),
+         reinterpret_cast<const void*>(&aid_attn_pp_kernel<bf16, AID_MODE_OUTER>)}};
+    static_assert(AID_MODE_PLAIN == 0 && AID_MODE_INNER == 1 && AID_MODE_OUTER == 2, "mode index");
+    const void* fn = fns[ti][a.mode];
+    if (!(*done & (1 << a.mode))) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        *done = true;
+        *done |= 1 << a.mode;
     }
     const int items = p.nqb * a.n_frames * a.heads;
     // persistent: the kernel owns every frame of the call (no early exits), every item is whole 8-tile trips, more items than CUs
@@ -635,9 +753,8 @@ hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) 
     const bool uniform = a.mode != AID_MODE_OUTER || knob == 1;
     p.persist = ((multi || a.mode == AID_MODE_PLAIN) && (a.l / PKT) % 8 == 0 && items > *ncu && *ncu % 8 == 0 && knob != 0 && uniform) ? 1 : 0;
     const int grid = p.persist ? *ncu : items;
-    if (ti == 0) hipLaunchKernelGGL(aid_attn_pp_kernel<f16>, dim3(grid), dim3(512), smem, stream, p);
-    else         hipLaunchKernelGGL(aid_attn_pp_kernel<bf16>, dim3(grid), dim3(512), smem, stream, p);
-    return hipGetLastError();
+    void* kargs[] = {const_cast<AttnPPParams*>(&p)};
+    return hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, smem, stream);
 }
 
 }  // namespace aid

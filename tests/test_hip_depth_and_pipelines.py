@@ -290,7 +290,8 @@ def test_n_frame_interpolate_end_to_end_vs_oracle_loop(guided):
 # head dims 40 / 80 / 160 / 64 kept, so the shipped kernels run) because the fp64 loop is bound by the weight bytes (SDXL: 8.4 GB of
 # fp64 weights per pass at full width); AID_E2E_FULL_WIDTH=1 runs the full widths (tools/refresh_profiles.sh does, once per round).
 # STATED TOLERANCE of the final latents after 50 steps (rel-L2 vs fp64; ~2x the measured values of profiles/r04_depth_parity.json):
-E2E50_BOUND = {("sd15", torch.float16): 1e-2, ("sdxl", torch.float16): 1e-2, ("sdxl", torch.bfloat16): 1e-1}
+# measured (round 4): SD1.5 fp16 1.3e-3 / 1.4e-3 (single / 7 frames), SDXL fp16 1.8e-3, SDXL bf16 1.5e-2 / 1.7e-2
+E2E50_BOUND = {("sd15", torch.float16): 4e-3, ("sdxl", torch.float16): 4e-3, ("sdxl", torch.bfloat16): 4e-2}
 E2E50 = [("sd15", torch.float16, "fused_inner"), ("sdxl", torch.bfloat16, "fused_outer"), ("sdxl", torch.float16, "fused_outer")]
 E2E50_N7 = E2E50 if os.environ.get("AID_E2E_ALL") == "1" else E2E50[:2]      # (the fp64 loop of a 14-frame SDXL run takes a minute)
 
