@@ -9,7 +9,7 @@
 //     M(t)   every MFMA of the tile in one burst: S(t) = K(t) Q'^T - m (8), then O^T += V^T(t-1) P(t-1)^T (8); in their shadow,
 //            one per MFMA and in pinned program order, the 16 operand-fragment reads: V^T(t-1) beside the score MFMAs, K(t+1)
 //            beside the PV MFMAs into the registers the score MFMAs released.  No VALU instruction.
-//     V(t)   the VALU half: head-room check, P(t) = 2^S(t), rounding to the storage type, row sums (v_dot2c); plus this wave's two
+//     V(t)   the VALU half: P(t) = 2^S(t), rounding to the storage type, row sums (v_dot2c), head-room test on the row sum; plus this wave's two
 //            LDS-DMA pieces of tile t + 6 and the counted wait that retires its pieces of tile t + 3
 //   so while one wave of a SIMD keeps the matrix pipe busy its partner does the exponentials, and vice versa.  In the
 //   program-order kernel the three co-resident waves of a SIMD drift into the same phase and MFMA time and VALU time add up
@@ -22,25 +22,13 @@
 //
 // Measured (profiles/r03_attn_notes.txt, same process): S = 4096 plain 597 us against 658 for the program-order kernel, fused outer
 // 1089 against 1213, fused inner 838 against 943; S = 1024 plain 107 against 95 (a 16-tile stream on one workgroup per CU).
-// aid_attn_fwd's default rule: fused OUTER from 1024 keys, everything else from 2048.
+// Round 4 (profiles/r04_attn_notes.txt): one instantiation per call mode, a DMA stream that never stops (no tail branches in the V
+// slot), head-room test on the row sum instead of a maximum chain: plain -4.2 %, outer -4.6 %, inner -5 % per launch.
+// aid_attn_fwd's default rule: fused OUTER / INNER from 1024 keys, everything else from 2048.
 #include <type_traits>
 
 #include "aid_common.hpp"
 #include "aid_kernels.hpp"
-
-// development switches of this file (tools/dev/pp_variants.py builds one library per setting; the defaults are the shipped kernel)
-#ifndef PP_CHAINS
-#define PP_CHAINS 1                     // independent partial row sums / maximum chains in the V slot (1 = one serial chain each)
-#endif
-#ifndef PP_ALWAYS_DMA
-#define PP_ALWAYS_DMA 0                 // 1: the DMA stream never stops (behind the last item it wraps into valid memory): no tail branches in the V slot
-#endif
-#ifndef PP_SPEC
-#define PP_SPEC 0                       // 1 (PLAIN / INNER instantiations): the maximum chains and half of the exponentials ride in the M slot's PV half
-#endif
-#ifndef PP_PRIO
-#define PP_PRIO 0                       // 1: static s_setprio 1 for the second wave group (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-#endif
 
 namespace aid {
 
@@ -93,7 +81,7 @@ __device__ __forceinline__ void slot_barrier() {
 }
 
 // MODE = the call's mode (AID_MODE_*): a PLAIN instantiation carries none of the segment machinery, an INNER one no parked state — the
-// registers that frees (34 + the scalar item records) pay for the speculative exponentials in the M slot (PP_SPEC)
+// registers and most of the scalar item records
 template <typename T, int MODE>
 __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) {
     typedef typename Vec<T>::v8 T8;
@@ -288,24 +276,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     float m = 0.f;
     bool fresh = true;
     f32x16 o[2], sc[2];
-    // row sum of the ROUNDED P over the 32 keys per tile this lane holds (the partner lane has the others), as NL independent
-    // partial sums: 16 v_dot2c in a row on ONE accumulator are a serial dependency chain (the dependent-issue latency, not the
-    // issue rate, then sets the pace of that part of the V slot)
-    constexpr int NL = PP_CHAINS;
-    float lsum[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) lsum[i] = 0.f;
-    auto lsum_total = [&]() __attribute__((always_inline)) {
-        float t = lsum[0];
-#pragma unroll
-        for (int i = 1; i < NL; ++i) t += lsum[i];
-        return t;
-    };
-    auto lsum_set = [&](float v) __attribute__((always_inline)) {
-        lsum[0] = v;
-#pragma unroll
-        for (int i = 1; i < NL; ++i) lsum[i] = 0.f;
-    };
+    float lsum = 0.f;                   // row sum of the ROUNDED P over the 32 keys per tile this lane holds (the partner lane has the others)
     T8 pf[4];
     f32x16 cneg;                        // -m as an accumulator block (C operand of a tile's first score MFMAs), rebuilt when m moves
     f32x16 po[2];                       // parked: O of the own-keys state while the begin side runs, then the finished begin side
@@ -341,28 +312,6 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 
     // operand fragments: kf = K(t + 1) for S(t + 1), vf = V^T(t) for O += V^T(t) P(t)^T, all four k-steps each
     T8 kf[4][2], vf[4][2];
-    // PP_SPEC: VALU work of tile t + 1 that rides between the PV MFMAs of M(t + 1), behind the score MFMAs that produced S(t + 1) — a
-    // wave alone in its V slot issues one VALU instruction per 5 - 6.5 cycles (11.4 for v_exp_f32) whatever the port could take, while
-    // the M-slot wave has ~6 idle issue slots per MFMA: four maximum chains over 8 scores each (xc) and the exponentials of the first
-    // 16 scores (pe), SPECULATIVE — formed against the current row reference; the V slot takes the rare slow path on xc and then
-    // recomputes them from the shifted scores, which stay intact in `sc`.
-    constexpr bool SPEC = PP_SPEC && MODE != AID_MODE_OUTER;
-    constexpr int NPE = PP_SPEC >= 2 ? 32 : 16;                 // speculative exponentials per tile (PP_SPEC = 2: all of them)
-    float xc[4], pe[NPE];
-    auto sflat = [&](int i) __attribute__((always_inline)) -> float { return sc[i >> 4][i & 15]; };
-    auto chain_links = [&](int c, int half) __attribute__((always_inline)) {       // two links of chain c (flat scores 8 c .. 8 c + 7)
-        const int b = 8 * c + 4 * half;
-        if (half == 0) xc[c] = fmaxf(fmaxf(sflat(b), sflat(b + 1)), fmaxf(sflat(b + 2), sflat(b + 3)));
-        else           xc[c] = fmaxf(fmaxf(xc[c], sflat(b)), fmaxf(fmaxf(sflat(b + 1), sflat(b + 2)), sflat(b + 3)));
-    };
-    auto spec_unit = [&](int u) __attribute__((always_inline)) {                   // unit u of 8: two chain links + NPE / 8 exponentials
-        chain_links(u >> 1, u & 1);
-#pragma unroll
-        for (int e = 0; e < NPE / 8; ++e) {
-            const int j = u * (NPE / 8) + e;
-            pe[j] = __builtin_amdgcn_exp2f(sc[j >> 4][j & 15]);
-        }
-    };
     auto lds_k = [&](int st, int ks, int b) __attribute__((always_inline)) {           // st: ring stage, a constant wherever it matters
         return *reinterpret_cast<const T8*>(smem + kad[ks] + (st * PTILE + b * 4096));
     };
@@ -397,66 +346,57 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             pin();
             kf[kk][w] = lds_k(sk, kk, w);                       // (kf[kk][w] was released by score MFMA 2 kk + w, eight or more MFMAs ago)
             pin();
-            if (SPEC && i >= 1) {                               // (the gap behind PV MFMA 0 is too close to the last score MFMA: hipcc pads it)
-                spec_unit(i - 1);
-                if (i == 7) spec_unit(7);
-                pin();
-            }
         }
     };
 
     // V slot: P(t) = 2^S(t) (row reference raised first when the head-room of the storage type is exceeded), rounded to the storage
     // type; this wave's two DMA pieces of tile t + LEAD; the counted wait that retires its pieces of tile t + 3
     constexpr int LEAD = 6;
-    auto retire = [&](int r) __attribute__((always_inline)) {   // r = tiles that may stay in flight behind the one being retired
-        if (r >= 3)      wait_vm<6>();
-        else if (r == 2) wait_vm<4>();
-        else if (r == 1) wait_vm<2>();
-        else             wait_vm<0>();
-    };
     auto vslot = [&](int t) __attribute__((always_inline)) {
-        const bool issue = PP_ALWAYS_DMA || has_next || t + LEAD < NT;
+        // The DMA stream never stops: behind the workgroup's last item it wraps into that item's first segment again (valid memory,
+        // nobody reads those stages), so the slot has no "is there a tile t + LEAD" branch and ONE counted wait — the tail logic cost
+        // 1.6 % (plain) to 6 % (inner) of the launch (profiles/r04_attn_notes.txt).
 #ifdef AID_ABLATIONS
         if (p.abl & 1) {                                        // 1: no VALU work in the V slot
-            if (!(p.abl & 2) && issue) dma_next((t + LEAD) & (PNS - 1));
+            if (!(p.abl & 2)) dma_next((t + LEAD) & (PNS - 1));
             fresh = false;
-            retire(has_next ? 3 : NT - 4 - t);
+            wait_vm<6>();
             return;
         }
+        if (!(p.abl & 2))
 #endif
-        if (issue
-#ifdef AID_ABLATIONS
-            && !(p.abl & 2)
-#endif
-        ) dma_next((t + LEAD) & (PNS - 1));
-        float xm;
-        if (SPEC) {
-            xm = fmaxf(fmaxf(xc[0], xc[1]), fmaxf(xc[2], xc[3]));
-        } else if (NL == 1) {
-            xm = fmaxf(sc[0][0], sc[0][1]);
+        dma_next((t + LEAD) & (PNS - 1));
+        // P(t) = 2^S(t) rounded to the storage type (lane (q, hi): sc[b][r] belongs to key 32 b + 16 (r >> 3) + 8 hi + (r & 7) of the tile
+        // = k-step 2 b + (r >> 3) of PV), and the tile's row sum of the ROUNDED values: v_dot2c against (1, 1), two keys per instruction,
+        // on two accumulators (the matrix pipe's ones-row block cost 4 of 20 MFMAs)
+        auto exp_tile = [&]() __attribute__((always_inline)) -> float {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x8 pv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
+                    pf[2 * b + u] = cvt8<T>(pv);
+                    const u32x4 w4 = __builtin_bit_cast(u32x4, pf[2 * b + u]);
+                    t0 = dot2_ones<T>(w4[0], t0); t1 = dot2_ones<T>(w4[1], t1);
+                    t0 = dot2_ones<T>(w4[2], t0); t1 = dot2_ones<T>(w4[3], t1);
+                }
+            return t0 + t1;
+        };
+        auto row_max = [&]() __attribute__((always_inline)) -> float {
+            float xm = fmaxf(sc[0][0], sc[0][1]);
 #ifdef AID_ABLATIONS
             if (!(p.abl & 8))                                   // 8: no head-room check (the maximum chain)
 #endif
 #pragma unroll
             for (int i = 1; i < 16; ++i) xm = fmaxf(fmaxf(xm, sc[i >> 3][(2 * i) & 15]), sc[i >> 3][(2 * i + 1) & 15]);
-        } else {                                                // NL independent chains over 32 / NL values each, then a short tree
-            float xc[NL];
-            constexpr int PER = 32 / NL;
-#pragma unroll
-            for (int c = 0; c < NL; ++c) {
-                const int b0 = c * PER;
-                xc[c] = fmaxf(sc[b0 >> 4][b0 & 15], sc[(b0 + 1) >> 4][(b0 + 1) & 15]);
-#pragma unroll
-                for (int i = 2; i < PER; i += 2)
-                    xc[c] = fmaxf(fmaxf(xc[c], sc[(b0 + i) >> 4][(b0 + i) & 15]), sc[(b0 + i + 1) >> 4][(b0 + i + 1) & 15]);
-            }
-            xm = xc[0];
-#pragma unroll
-            for (int c = 1; c < NL; ++c) xm = fmaxf(xm, xc[c]);
-        }
-        if (fresh || __any(xm > XTH)) {
-            // slow path (first tile of the row, or a score out-grew the head-room): move the reference to the row maximum,
-            // rescale O (its ones row = l included) and shift this tile's arguments; PV(t - 1) is complete, O is at rest
+            return xm;
+        };
+        // slow path (first tile of the row, or a score out-grew the head-room of the storage type): move the reference to the row
+        // maximum, rescale O and l and shift this tile's arguments; PV(t - 1) is complete, O is at rest
+        auto raise = [&](float xm) __attribute__((always_inline)) {
             const float rowmax = max_halves(xm);
             const float shift = fresh ? rowmax : fmaxf(rowmax, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-shift);
@@ -466,38 +406,24 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             asm volatile("" : "+v"(cneg));                      // (opaque: keeps hipcc from rebuilding the block in every M slot)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-#pragma unroll
-            for (int i = 0; i < NL; ++i) lsum[i] *= alpha;
+            lsum *= alpha;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[b][r] -= shift;
             fresh = false;
-            if (SPEC) {
-#pragma unroll
-                for (int r = 0; r < NPE; ++r) pe[r] = __builtin_amdgcn_exp2f(sc[r >> 4][r & 15]);
-            }
+        };
+        // Exponentiate first, test afterwards: the scores stay intact in `sc`, so a tile whose row sum shows that an argument out-grew
+        // the head-room (sum of this lane's 32 values above 2^XTH; an f32 / storage-type overflow arrives as +inf and tests true as well)
+        // is simply redone against the raised reference.  The sixteen v_max3 of a per-tile maximum chain become one compare:
+        // -2.7 ... -3.1 % per launch (profiles/r04_attn_notes.txt); every P that reaches the PV product is <= 2^XTH as before.
+        float ts = fresh ? 0.f : exp_tile();
+        if (fresh || __any(ts > __builtin_amdgcn_exp2f(XTH))) {
+            raise(row_max());
+            ts = exp_tile();
         }
-        // lane (q, hi): sc[b][r] belongs to key 32 b + 16 (r >> 3) + 8 hi + (r & 7) of the tile = k-step 2 b + (r >> 3) of PV
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f32x8 pv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    pv[e] = (SPEC && 16 * b + 8 * u + e < NPE) ? pe[(16 * b + 8 * u + e) % NPE] : __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
-                pf[2 * b + u] = cvt8<T>(pv);
-            }
-        // row sums of the rounded P: v_dot2c against (1, 1), two keys per instruction (the matrix pipe's ones-row block cost 4 of 20 MFMAs)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x4 w4 = __builtin_bit_cast(u32x4, pf[i]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) lsum[(4 * i + e) % NL] = dot2_ones<T>(w4[e], lsum[(4 * i + e) % NL]);
-        }
-        if (issue) wait_vm<6>();                                // steady state: the three tiles behind t + 3 stay in flight
-        else       retire(NT - 4 - t);                          // (last item: the stream has run out)
+        lsum += ts;
+        wait_vm<6>();                                           // retires tile t + 3: the three tiles behind it stay in flight
     };
 
     // Segment boundaries of a two-sided frame.  S(t) of the next segment's first tile is in `sc` and PV(t - 1) closed the segment
@@ -505,12 +431,11 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     auto park = [&]() __attribute__((always_inline)) {          // own keys done: park the state, the begin side continues on it
 #pragma unroll
         for (int r = 0; r < 16; ++r) { po[0][r] = o[0][r]; po[1][r] = o[1][r]; }
-        pl = lsum_total();
+        pl = lsum;
         pm = m;
     };
     auto swap_sides = [&]() __attribute__((always_inline)) {    // begin side done: keep (1 - c) O_b / l_b, resume the own-keys state
-        const float lown = lsum_total();
-        const float lrow = lown + other_half(lown);             // (all lanes take part in the exchange)
+        const float lrow = lsum + other_half(lsum);             // (all lanes take part in the exchange)
         const float wb = w_b / lrow;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -520,7 +445,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 o[d][r] = po[d][r];
                 po[d][r] = rb;
             }
-        lsum_set(pl);
+        lsum = pl;
         const float back = m - pm;                              // S(t) was formed against the begin side's reference (>= the parked one)
         m = pm;
 #pragma unroll
@@ -545,8 +470,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             return;
         }
 #endif
-        const float lfin = lsum_total();
-        const float inv = w_e / (lfin + other_half(lfin));      // (w_e = 1 unless this frame mixes two sides)
+        const float inv = w_e / (lsum + other_half(lsum));      // (w_e = 1 unless this frame mixes two sides)
         const int q = q0 + l31;
         if (q < a.s) {
             const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
@@ -587,20 +511,16 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // ---- prologue: pieces of tiles 0 .. 5 requested, 0 .. 2 retired and published; S(0); fragments of K(1) ----------------
 #pragma unroll
     for (int t = 0; t < LEAD; ++t)
-        if (PP_ALWAYS_DMA || t < NT) dma_next(t);
+        dma_next(t);
 #ifdef AID_ABLATIONS
     if (p.abl & 32) { tl[1] = clock64(); asm volatile("" :: "v"(qf[0]), "v"(qf[3])); }
 #endif
-    if (PP_ALWAYS_DMA) wait_vm<6>();
-    else               retire(NT - 3);
+    wait_vm<6>();
 #ifdef AID_ABLATIONS
     if (p.abl & 32) tl[2] = clock64();
 #endif
     slot_barrier();
     if (grp == 1) slot_barrier();                               // the second group runs one barrier behind
-#if PP_PRIO
-    if (grp == 1) __builtin_amdgcn_s_setprio(1);                // (grp comes from a readfirstlane: a scalar branch around one s_setprio)
-#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) kf[i >> 1][i & 1] = lds_k(0, i >> 1, i & 1);
     f32x16 zacc;
@@ -617,12 +537,6 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         for (int i = 0; i < 8; ++i) kf[i >> 1][i & 1] = lds_k(1, i >> 1, i & 1);      // nt >= 2
     }
     settle();
-    if (SPEC) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) chain_links(i >> 1, i & 1);
-#pragma unroll
-        for (int r = 0; r < NPE; ++r) pe[r] = 0.f;              // (tile 0 takes the slow path and recomputes them)
-    }
     slot_barrier();
 #ifdef AID_ABLATIONS
     if (p.abl & 32) tl[3] = clock64();
@@ -678,7 +592,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         if (!has_next) break;
         // the next item: its S(0) is in `sc`; everything else starts over
         fresh = true;
-        lsum_set(0.f);
+        lsum = 0.f;
         pl = 0.f;
         pm = 0.f;
 #pragma unroll
@@ -690,7 +604,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         adopt();
         dseg = 0;                                               // the DMA stream is LEAD tiles into this item's first segment already
     }
-    if (PP_ALWAYS_DMA) wait_vm<0>();                            // (the wrapped requests behind the last item: nobody reads them)
+    wait_vm<0>();                            // (the wrapped requests behind the last item: nobody reads them)
     if (grp == 0) slot_barrier();                               // both groups pass the same number of barriers
 }
 
