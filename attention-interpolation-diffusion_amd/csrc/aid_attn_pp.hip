@@ -44,6 +44,8 @@ struct AttnPPParams {
     int32_t nqb;                        // 256-row q blocks per (frame, head)
     int32_t multi;                      // 1: this launch runs every frame of the call (it is the only launch)
     int32_t persist;                    // 1: one workgroup per CU walks several items (every item is whole 8-tile trips)
+    int32_t hv_lo, hv_hi, hv_units;     // persistent walk: frames [hv_lo, hv_hi) are HEAVY (hv_units key segments instead of one) — a
+                                        // balance hint from the host's view of the call; results never depend on it
     float   c2;                         // softmax_scale * log2(e)
 #ifdef AID_ABLATIONS
     int32_t abl;                        // development builds only: timing ablations, results are garbage
@@ -100,22 +102,61 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     const int grp = wave >> 2;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // ---- work items: 256 query rows of one (frame, head); order [head][frame][q block] so a (frame, head)'s blocks share an L2, the
-    // three-segment frames first inside every XCD's range.  p.persist == 0: one item per workgroup (hardware dispatch order).
-    // p.persist == 1 (every item is whole 8-tile trips): one workgroup per CU; workgroup b sits on XCD b % 8 and walks ITS XCD's range
-    // in SNAKE order — positions w, 2 W - 1 - w, 2 W + w, ... (w = b / 8, W = workgroups per XCD) — which balances the 3 : 1 mix of heavy
-    // and light items statically (plain round-robin left the first workgroups with all the extra heavy items: -14 %).  The tile stream,
-    // the DMA ring and the slot alternation run on across an item boundary, so a workgroup's ~5 us start-up (dispatch, scalar loads, Q
-    // and six tiles in flight, first product; tools/dev/pp_timeline.py) is paid once per launch instead of once per item.
+    // ---- work items: 256 query rows of one (frame, head).
+    // p.persist == 0: one item per workgroup in hardware dispatch order; logical order [head][frame][q block], every XCD a contiguous
+    // range of it, the three-segment frames first inside the range.
+    // p.persist == 1 (every item is whole 8-tile trips): one workgroup per CU; workgroup b sits on XCD b % 8 and walks a STATIC,
+    // BALANCED share of its XCD's items (w = b / 8 of W workgroups per XCD).  An XCD owns a contiguous range of (head, q block) PAIRS,
+    // every pair with all its frames — so every XCD holds the same mix of heavy frames (hv_units key segments) and light ones (one
+    // segment), and a (frame, head)'s q blocks still meet in one L2 (contiguous ranges of the [head][frame][q block] order cut through
+    // heads: S = 4096, 7 + 7 frames put 520 segment-units on one XCD and 440 on another).  Inside the XCD the heavy items, ordered
+    // [frame][pair], are dealt cyclically (w, w + W, ...); then the light items first level the workgroups that got one heavy item
+    // less (hv_units light items each), and the rest is dealt cyclically again: S = 4096 gives every workgroup exactly 15
+    // segment-units, S = 1024 7 or 8 (profiles/r04_attn_notes.txt; round 3's snake order could not balance the 3 : 1 mix of a fused
+    // OUTER call, which therefore paid a workgroup's ~5 us start-up per ITEM).  The tile stream, the DMA ring and the slot alternation
+    // run on across an item boundary, so the start-up (dispatch, scalar loads, Q and six tiles in flight, first product) is paid once
+    // per launch.  The walk is a pure function of (block, j): no atomics, the same result bit for bit run to run.
     const int nt = a.l / PKT;                                   // tiles per key segment
     const int n_items = p.nqb * a.n_frames * a.heads;
     const int n_heavy = a.n_frames - a.n_plain;
     const bool hf = p.multi && a.n_plain > 0 && n_heavy > 0;
     const int xcd = blockIdx.x & 7, wx = blockIdx.x >> 3, WX = gridDim.x >> 3;
-    auto vblock = [&](int j) __attribute__((always_inline)) {   // virtual block id of this workgroup's j-th item (>= n_items: none)
-        if (!p.persist) return j == 0 ? (int)blockIdx.x : n_items;
-        const int pos = j * WX + ((j & 1) ? WX - 1 - wx : wx);
-        return xcd + 8 * pos;
+    const int nhf = p.hv_hi - p.hv_lo;                          // heavy frames
+    int pb = 0, npx = 0;                                        // this XCD's pairs [pb, pb + npx)
+    if (p.persist) {
+        const int np = a.heads * p.nqb, q = np >> 3, r = np & 7;
+        pb = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        npx = q + (xcd < r ? 1 : 0);
+    }
+    // this workgroup's j-th item as a logical id of the [head][frame][q block] order (>= n_items: none)
+    auto item_lid = [&](int j) __attribute__((always_inline)) {
+        if (!p.persist) {
+            if (j != 0) return n_items;
+            return hf ? heavy_first((int)blockIdx.x, n_items, n_heavy * p.nqb, a.n_frames * p.nqb) : xcd_remap((int)blockIdx.x, n_items);
+        }
+        const int nhx = npx * nhf, nlx = npx * (a.n_frames - nhf);
+        const int hq = nhx / WX, hr = nhx % WX;
+        const int hc = hq + (wx < hr ? 1 : 0);                  // heavy items of this workgroup
+        int t, fr;
+        if (j < hc) {
+            t = wx + j * WX;                                    // t-th heavy item of the XCD, order [frame][pair]
+            fr = p.hv_lo + t / npx;
+        } else {
+            const int jj = j - hc;
+            const int ndef = hr > 0 ? WX - hr : 0;              // workgroups one heavy item short
+            const int p2 = min(nlx, p.hv_units * ndef);         // light items [0, p2) level them
+            const int c1 = (hr > 0 && wx >= hr) ? max(min(p.hv_units * (wx - hr + 1), p2) - p.hv_units * (wx - hr), 0) : 0;
+            if (jj < c1) {
+                t = p.hv_units * (wx - hr) + jj;
+            } else {
+                t = p2 + wx + (jj - c1) * WX;
+                if (t >= nlx) return n_items;
+            }
+            const int fi = t / npx;                             // t-th light item of the XCD
+            fr = fi < p.hv_lo ? fi : fi + nhf;
+        }
+        const int pi = pb + t % npx;
+        return ((pi / p.nqb) * a.n_frames + fr) * p.nqb + pi % p.nqb;
     };
     // Key segments of a frame (the same decisions aid_attn_kernel takes, on the same device coefficients):
     //   single  — PLAIN call, negative coefficient (PLAIN rider of a batched-CFG call), fused END-POINT frame: own keys only.
@@ -133,8 +174,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     int N_park = -1, N_swap = -1;
     float N_wb = 0.f, N_we = 1.f;
     bool N_skip = false;
-    auto plan = [&](int vb) __attribute__((always_inline)) {
-        const int lid = hf ? heavy_first(vb, n_items, n_heavy * p.nqb, a.n_frames * p.nqb) : xcd_remap(vb, n_items);
+    auto plan = [&](int lid) __attribute__((always_inline)) {
         const int qb = lid % p.nqb;
         N_fr = (lid / p.nqb) % a.n_frames;
         N_h = lid / (p.nqb * a.n_frames);
@@ -179,7 +219,11 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         t2mask = N_t2; park_at = N_park; swap_at = N_swap; w_b = N_wb; w_e = N_we;
         NT = nseg * nt;
     };
-    plan(vblock(0));
+    {
+        const int first = item_lid(0);
+        if (first >= n_items) return;                           // a persistent workgroup the deal left empty (fewer items than the balance needs)
+        plan(first);
+    }
     if (N_skip) return;                                         // (split launches are never persistent)
     adopt();
 
@@ -546,7 +590,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // right before that M slot) or, for the workgroup's last item, stale ring bytes whose scores nobody reads.
 #pragma nounroll
     for (int j = 0;; ++j) {
-        const int vbn = vblock(j + 1);
+        const int vbn = item_lid(j + 1);
         has_next = vbn < n_items;
         if (has_next) {
             plan(vbn);
@@ -664,8 +708,14 @@ hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) 
     const int knob = tune(TUNE_ATTN_PIPE);                      // development: 0 = one item per workgroup
     // (measured: plain S = 4096 582 -> 560 us, S = 1024 108 -> 94, inner 808 -> 800 / 129 -> 122; the 3 : 1 item mix of an OUTER call is
     //  balanced as well by the hardware's dynamic dispatch as by the static snake order: 1048 vs 1047, 160 vs 160 — one item per workgroup)
-    const bool uniform = a.mode != AID_MODE_OUTER || knob == 1;
-    p.persist = ((multi || a.mode == AID_MODE_PLAIN) && (a.l / PKT) % 8 == 0 && items > *ncu && *ncu % 8 == 0 && knob != 0 && uniform) ? 1 : 0;
+    p.persist = ((multi || a.mode == AID_MODE_PLAIN) && (a.l / PKT) % 8 == 0 && items > *ncu && *ncu % 8 == 0 && knob != 0) ? 1 : 0;
+    // which frames walk several key segments (host's view: the AID frames of a call sit in front of its PLAIN riders, a fused call's
+    // end-point frames walk their own keys only): a hint for the static balance of the persistent walk
+    const int n_aid = a.n_frames - a.n_plain;
+    p.hv_lo = p.hv_hi = 0;
+    p.hv_units = 1;
+    if (a.mode == AID_MODE_OUTER && n_aid > 2) { p.hv_lo = 1; p.hv_hi = n_aid - 1; p.hv_units = a.fused ? 3 : 2; }
+    if (a.mode == AID_MODE_INNER && a.fused && n_aid > 2) { p.hv_lo = 1; p.hv_hi = n_aid - 1; p.hv_units = 2; }
     const int grid = p.persist ? *ncu : items;
     void* kargs[] = {const_cast<AttnPPParams*>(&p)};
     return hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, smem, stream);

@@ -204,12 +204,15 @@ def test_default_rule_for_the_pingpong_kernel(tuning):
         assert ("aid_attn_pp" in ops.last_attn_variant()) == want, (l, mode, fused, ops.last_attn_variant())
 
 
+@pytest.mark.parametrize("h", [20, 5], ids=["h20", "h5"])
 @pytest.mark.parametrize("mode,fused", [("outer", True), ("inner", True), ("inner", False), ("outer", False), ("plain", False)])
-def test_persistent_workgroups_at_the_sdxl_level_shape(mode, fused, tuning):
+def test_persistent_workgroups_at_the_sdxl_level_shape(mode, fused, h, tuning):
     """S = 1024, 7 AID frames + 7 riders, 20 heads = 1120 items on 256 persistent workgroups (ATTN_PIPE = 1 forces the persistent walk
     for the mixed OUTER call too): the tile stream runs across item boundaries, the next item's Q rows come back from LDS, parked /
-    swapped states start over per item.  Against the program-order kernel (itself held against the oracle) on the whole tensor."""
-    dtype, n, s, h = torch.bfloat16, 7, 1024, 20
+    swapped states start over per item.  Against the program-order kernel (itself held against the oracle) on the whole tensor.
+    Round 4: the walk is a static balanced deal of heavy / light items per XCD (h = 5: 20 (head, q block) pairs do not divide over
+    the 8 XCDs, some workgroups get no heavy item)."""
+    dtype, n, s = torch.bfloat16, 7, 1024
     q, k, v, vt = _inputs(2 * n, s, s, h, dtype, seed=31)
     coef = torch.from_numpy(O.beta_coefs(n, 50, 50)).float()
     coef[0], coef[-1] = 0, 1
