@@ -1754,7 +1754,7 @@ static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char**
         pp = cost_pp < 0.95 * cost_ls;
         if (force == 31) pp = true;
     }
-    if (force == 7 || force == 9 || force == 10) pp = false;
+    if (force == 7) pp = false;
     if (pp && prefer_ppx(g, ncu, pl)) {
         if (dry) { *is_ppx = true; return hipSuccess; }
         if (variant) *variant = "pingpong288";
@@ -1764,10 +1764,6 @@ static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char**
     if (pp) plan_pp(g, ncu, g.p[0].k / 64);             // g.tile_start back in 256 x 256 units
     if (variant) *variant = !pp ? "lockstep128" : pl.n_small ? "pingpong256+tail128" : "pingpong256";
     if (pp) return launch_pp<T>(g, stream, pl, sd);
-    bool k32 = true;
-    for (int i = 0; i < g.n_problems; ++i) k32 = k32 && g.p[i].k % 32 == 0;
-    if (force == 9 && k32)  { if (variant) *variant = "lockstep128/k32x4"; return launch_pipe<T, 128, 128, 32, 4, 2, 4>(g, stream); }
-    if (force == 10 && k32) { if (variant) *variant = "lockstep128/k32x5"; return launch_pipe<T, 128, 128, 32, 5, 2, 4>(g, stream); }
     return launch_pipe<T, 128, 128, 64, 2, 2, 4>(g, stream);       // 8 waves, 64 x 32 wave tiles, 2 workgroups / CU
 }
 
