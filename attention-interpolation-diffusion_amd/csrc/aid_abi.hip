@@ -162,6 +162,7 @@ int check_processor(const AidProcessorArgs& a) {
     }
     if ((a.k_cached != nullptr) != (a.vt_cached != nullptr)) return AID_ERR_ARG;
     if (a.k_cached && (!a.ctx || !aligned16(a.k_cached) || !aligned16(a.vt_cached))) return AID_ERR_ARG;
+    if (a.kv_cached_lt != 0 && (!a.k_cached || a.mode == AID_MODE_INNER || a.kv_cached_lt % 64 || a.kv_cached_lt < a.l)) return AID_ERR_ARG;
     if (!(a.ln_eps >= 0.f)) return AID_ERR_ARG;
     if (a.ln_eps > 0.f) {
         if (!aid::layernorm_width_supported(a.c)) return AID_ERR_SHAPE;
@@ -391,6 +392,20 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     const bool alone = a.mode == AID_MODE_PLAIN || (a.l % 512 == 0 && (a.mode == AID_MODE_OUTER || (a.k2 && a.vt2)));
     const bool dflt = a.l >= ((a.mode == AID_MODE_PLAIN || (a.mode == AID_MODE_OUTER && !a.fused)) ? 2048 : 1024);
     const int v2 = aid::tune(aid::TUNE_ATTN_V2);
+    // short key streams with padded keys / values (the cached text keys of cross-attention, l = 77): the short-stream ping-pong
+    // kernel can run the whole call (aid_attn_xs.hip).  NOT the default: measured 5 - 20 % slower than aid_attn_kernel on the stacks'
+    // 77-key launches (a 256-row item is two tiles long — its per-item cost is as large as its work; profiles/r04_attn_notes.txt);
+    // ATTN_V2 = 1 selects it (parity suite tests/test_hip_attn_short.py)
+    if (v2 == 1 && aid::attn_xs_supported(a)) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "aid_attn_xs<%s,d64%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.mode == AID_MODE_OUTER ? ",outer" : "");
+        {
+            ProfScope ps(static_cast<hipStream_t>(stream), nm, flops, bytes, flops_exec);
+            e = aid::attn_xs_launch(a, static_cast<hipStream_t>(stream));
+        }
+        g_variant = a.mode == AID_MODE_OUTER ? "aid_attn_xs<d64,outer>" : "aid_attn_xs<d64>";
+        return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
+    }
     const bool use_pp = aid::attn_pp_supported(a) && (alone || n_single > 0) &&
                         (v2 == 1 || (v2 < 0 && alone && dflt));
     if (use_pp) {
@@ -547,6 +562,11 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     at.s = a.s; at.l = l; at.heads = a.heads; at.d = d;
     at.ldq = a.c; at.ldk = a.c; at.ldvt = cv.lp; at.ldo = a.c;
     at.q_fs = (int64_t)a.s * a.c; at.k_fs = (int64_t)l * a.c; at.vt_fs = (int64_t)a.c * cv.lp; at.o_fs = (int64_t)a.s * a.c;
+    if (cached && a.kv_cached_lt > 0) {        // keys / values padded to whole tiles by the caller (short-stream ping-pong kernel)
+        at.ldvt = a.kv_cached_lt;
+        at.k_fs = (int64_t)a.kv_cached_lt * a.c; at.vt_fs = (int64_t)a.c * a.kv_cached_lt;
+        at.kv_padded = 1;
+    }
     at.mode = a.mode; at.fused = a.fused; at.begin = a.begin; at.end = a.end;
     at.accumulate = 0; at.dtype = a.dtype;
     at.softmax_scale = 1.0f / sqrtf((float)d);

@@ -502,7 +502,10 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         if (park_at < 0) fresh = true;                          // pure OUTER: the end side starts from the empty state
     };
 
-    // O / l of the finished item; lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3}
+    // O / l of the finished item; lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3}.  The wave's 32 x 64 block goes through ITS
+    // 4 KB of LDS behind the ring (the next item's Q rows were read out of it before the last M slot; a persistent walk requests the
+    // item after that only at the top of the next item) and leaves as four 16-byte stores per lane covering whole 128-byte rows: eight
+    // 8-byte stores per lane at a row stride are store-ISSUE bound (~1.4 us per item measured on the short-stream kernel; the guide's T21).
     auto finish = [&]() __attribute__((always_inline)) {
 #ifdef AID_ABLATIONS
         if (p.abl & (16 | 32)) {                                // slot timing / workgroup timeline instead of the result
@@ -515,25 +518,52 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         }
 #endif
         const float inv = w_e / (lsum + other_half(lsum));      // (w_e = 1 unless this frame mixes two sides)
-        const int q = q0 + l31;
-        if (q < a.s) {
-            const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
-            T* orow = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q * a.ldo + h * D;
+        if (q0 >= a.s) return;                                  // (wave-uniform: a wave past the last row)
+        const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
+        if (MODE == AID_MODE_OUTER) {
+            // (the OUTER instantiation sits at 250 of 256 registers with the parked state: it keeps the 8-byte row-per-lane stores — its
+            //  items are two or three key segments long, the store tail is <= 3 % of an item)
+            const int q = q0 + l31;
+            if (q < a.s) {
+                T* orow = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q * a.ldo + h * D;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int dv_ = 32 * d + 8 * g + 4 * hi;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (o[d][4 * g + e] * inv + po[d][4 * g + e]) * osc;      // po: the begin side, or zero
+                        if (a.accumulate) v += up4<T>(*reinterpret_cast<const T4*>(orow + dv_));
+                        *reinterpret_cast<T4*>(orow + dv_) = cvt4<T>(v);
+                    }
+            }
+        } else {
+            // stage: 16-byte chunk c = 4 d + g of row r sits at slot c ^ swz(r) (two-way conflicts at most on the 8-byte writes)
+            char* const st = qlds;
+            const int wsw = (l31 >> 1) & 7;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int dv_ = 32 * d + 8 * g + 4 * hi;
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float r_ = o[d][4 * g + e] * inv;
-                        if (MODE == AID_MODE_OUTER) r_ += po[d][4 * g + e];      // the begin side, or zero
-                        v[e] = r_ * osc;
-                    }
-                    if (a.accumulate) v += up4<T>(*reinterpret_cast<const T4*>(orow + dv_));
-                    *reinterpret_cast<T4*>(orow + dv_) = cvt4<T>(v);
+                    for (int e = 0; e < 4; ++e) v[e] = o[d][4 * g + e] * inv * osc;
+                    *reinterpret_cast<T4*>(st + l31 * 128 + (((4 * d + g) ^ wsw) << 4) + 8 * hi) = cvt4<T>(v);
                 }
+            // read back row-major: lane -> (row lane / 8 + 8 i, chunk lane % 8), one whole 128-byte row per eight lanes
+            const Rsrc ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7fffffff, 0x00020000);     // (built here: no SGPRs held across the item)
+            const int so = (int)(((int64_t)fr * a.o_fs + h * D) * 2);
+            const int rr = lane >> 3, cc = lane & 7;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rr + 8 * i;
+                T8 v = *reinterpret_cast<const T8*>(st + row * 128 + ((cc ^ ((row >> 1) & 7)) << 4));
+                const int q = q0 + row;
+                const int vo = (min(q, a.s - 1) * a.ldo + cc * 8) * 2;
+                if (a.accumulate) v = cvt8<T>(up8<T>(v) + up8<T>(__builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(ro, vo, so, 0))));
+                if (q < a.s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, so, 0);
+            }
         }
     };
 
@@ -662,11 +692,11 @@ bool attn_pp_supported(const AidAttnArgs& a) {
     const int64_t kb = (int64_t)a.n_kv * a.k_fs * 2, vb = (int64_t)a.n_kv * a.vt_fs * 2;
     const int64_t k2b = a.mode == AID_MODE_INNER ? (int64_t)a.n_frames * a.k_fs * 2 : 0;
     const int64_t v2b = a.mode == AID_MODE_INNER ? (int64_t)a.n_frames * a.vt_fs * 2 : 0;
-    const int64_t qb = (int64_t)a.n_frames * a.q_fs * 2;
+    const int64_t qb = (int64_t)a.n_frames * a.q_fs * 2, ob = (int64_t)a.n_frames * a.o_fs * 2;
     const uintptr_t al = reinterpret_cast<uintptr_t>(a.k) | reinterpret_cast<uintptr_t>(a.vt) | reinterpret_cast<uintptr_t>(a.k2) |
-                         reinterpret_cast<uintptr_t>(a.vt2);                               // LDS-DMA moves 16-byte pieces
+                         reinterpret_cast<uintptr_t>(a.vt2) | reinterpret_cast<uintptr_t>(a.out);   // LDS-DMA / output rows: 16-byte pieces
     return a.d == 64 && a.l % PKT == 0 && a.l >= 2 * PKT && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.k_fs % 8 == 0 && a.vt_fs % 8 == 0 &&
-           (al & 15) == 0 && kb < lim && vb < lim && k2b < lim && v2b < lim && qb < lim;
+           (al & 15) == 0 && kb < lim && vb < lim && k2b < lim && v2b < lim && qb < lim && ob < lim && a.ldo % 8 == 0 && a.o_fs % 8 == 0;
 }
 
 hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi) {

@@ -72,6 +72,9 @@ hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** va
 // d = 64 ping-pong kernel for the single-segment frames of a call (aid_attn_pp.hip); frames with more segments exit at once
 bool       attn_pp_supported(const AidAttnArgs& a);
 hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi);
+// d = 64 ping-pong kernel for SHORT key streams (text cross-attention; aid_attn_xs.hip): whole PLAIN / OUTER calls with padded keys / values
+bool       attn_xs_supported(const AidAttnArgs& a);
+hipError_t attn_xs_launch(const AidAttnArgs& a, hipStream_t stream);
 bool       attn_head_dim_supported(int d);
 hipError_t lerp_kv_launch(const void* k, const void* vt, void* k2, void* vt2, const float* coef, int n_frames, int begin,
                           int end, int64_t k_fs, int64_t vt_fs, int dtype, hipStream_t stream);

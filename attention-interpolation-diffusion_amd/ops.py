@@ -201,12 +201,22 @@ def ln_fold(w: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch
     return wf, cs, sh
 
 
-def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, extra_rows: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, extra_rows: int = 0, padded: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """k = e @ wk.T  [F, L, C]  and  V^T = wv @ e^T  [F, C, Lp]  (Lp = L rounded up to 8) in one launch.
     ``extra_rows``: allocate that many more (uninitialised) frame rows behind the F projected ones — room for the
-    end-point frames' keys / values a rank receives from their owners (dist.EndpointExchange)."""
+    end-point frames' keys / values a rank receives from their owners (dist.EndpointExchange).
+    ``padded``: the layout of ``AidAttnArgs.kv_padded`` / ``AidProcessorArgs.kv_cached_lt`` — k [F, Lt, C], V^T [F, C, Lt] with
+    Lt = L rounded up to 64, rows / columns L .. Lt zero: short key streams (text cross-attention) then run on the short-stream
+    ping-pong kernel.  Callers read the first L rows / columns (``k[:, :L]``, ``vt[:, :, :L]``)."""
     f, l, cc = e.shape
     c = wk.shape[0]
+    if padded:
+        lt = (l + 63) // 64 * 64
+        k = torch.zeros(f + extra_rows, lt, c, dtype=e.dtype, device=e.device)
+        vt = torch.zeros(f + extra_rows, c, lt, dtype=e.dtype, device=e.device)
+        gemm_nt([dict(a=e, b=wk, c=k, m=l, n=c, k=cc, lda=cc, ldb=cc, ldc=c, batch=f, stride_a=l * cc, stride_b=0, stride_c=lt * c),
+                 dict(a=wv, b=e, c=vt, m=c, n=l, k=cc, lda=cc, ldb=cc, ldc=lt, batch=f, stride_a=0, stride_b=l * cc, stride_c=c * lt)])
+        return k, vt
     lp = (l + 7) // 8 * 8
     k = torch.empty(f + extra_rows, l, c, dtype=e.dtype, device=e.device)
     vt = torch.empty(f + extra_rows, c, lp, dtype=e.dtype, device=e.device)
@@ -223,9 +233,11 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
              begin: int = 0, end: int = -1, out: Optional[torch.Tensor] = None,
              accumulate: bool = False, out_scale: float = 1.0,
              frame_scale: Optional[torch.Tensor] = None, kv_map: Optional[torch.Tensor] = None,
-             softmax_scale: Optional[float] = None, n_plain: int = 0, seg_executed: int = 0) -> torch.Tensor:
+             softmax_scale: Optional[float] = None, n_plain: int = 0, seg_executed: int = 0,
+             kv_padded: bool = False, q_prescaled: bool = False) -> torch.Tensor:
     """Interpolated attention core (see AidAttnArgs in include/aid_hip.h).
-    q [N, S, C], k [F, L, C], vt [F, C, Lp] contiguous; coef / frame_scale fp32 device [N]."""
+    q [N, S, C], k [F, L, C], vt [F, C, Lp] contiguous; coef / frame_scale fp32 device [N].  ``kv_padded``: k / vt come from
+    ``project_kv(padded=True)`` ([F, Lt, C] / [F, C, Lt], zero beyond L)."""
     lib = _lib.load()
     _require_gpu(q, k, vt, out, coef, frame_scale, kv_map)
     dt = _dtype_code(q)
@@ -268,6 +280,8 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
     a.out_scale = float(out_scale)
     a.n_plain = int(n_plain)
     a.seg_executed = int(seg_executed)
+    a.kv_padded = int(bool(kv_padded))
+    a.q_prescaled = int(bool(q_prescaled))              # q already holds q * softmax_scale * log2(e) (the processor path's q projection)
     with _on(q.device):
         _lib.check(lib.aid_attn_fwd(C.byref(a), _stream()), "aid_attn_fwd")
     return out
@@ -390,12 +404,16 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
             raise ValueError("cached keys / values belong to a cross-attention call")
         kc, vc = kv_cached
         _require_gpu(kc, vc)
-        lp = (ctx.shape[1] + 7) // 8 * 8
-        if kc.dtype != x.dtype or vc.dtype != x.dtype or not kc.is_contiguous() or not vc.is_contiguous() \
-                or kc.shape[0] < ctx.shape[0] or tuple(kc.shape[1:]) != (ctx.shape[1], c) \
-                or vc.shape[0] < ctx.shape[0] or tuple(vc.shape[1:]) != (c, lp):
-            raise ValueError("kv_cached must be (k [n_ctx, L, C], vt [n_ctx, C, round_up(L, 8)]) as project_kv returns them")
+        lp, lt = (ctx.shape[1] + 7) // 8 * 8, (ctx.shape[1] + 63) // 64 * 64
+        ok = kc.dtype == x.dtype and vc.dtype == x.dtype and kc.is_contiguous() and vc.is_contiguous() \
+            and kc.shape[0] >= ctx.shape[0] and vc.shape[0] >= ctx.shape[0]
+        compact = ok and tuple(kc.shape[1:]) == (ctx.shape[1], c) and tuple(vc.shape[1:]) == (c, lp)
+        padded = ok and tuple(kc.shape[1:]) == (lt, c) and tuple(vc.shape[1:]) == (c, lt) and mode != "inner"
+        if not (compact or padded):
+            raise ValueError("kv_cached must be (k [n_ctx, L, C], vt [n_ctx, C, round_up(L, 8)]) or, padded to whole key tiles, "
+                             "(k [n_ctx, Lt, C], vt [n_ctx, C, Lt]) with Lt = round_up(L, 64) — as project_kv returns them")
         a.k_cached, a.vt_cached = kc.data_ptr(), vc.data_ptr()
+        a.kv_cached_lt = 0 if compact else lt
     nbytes = lib.aid_processor_workspace_bytes(C.byref(a))
     with _on(dev):
         if nbytes == 0:

@@ -317,15 +317,26 @@ def _vkey(t: torch.Tensor):
     return None if v is None else (t.data_ptr(), v)
 
 
-def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tensor):
+def _kv_padded_layout() -> bool:
+    """The tile-padded layout of the cached text keys / values serves the short-stream ping-pong kernel, which is opt-in
+    (development knob ATTN_V2 = 1, profiles/r04_attn_notes.txt); by default the cache keeps the compact layout."""
+    try:
+        return ops.get_tuning("ATTN_V2") == 1
+    except RuntimeError:
+        return False
+
+
+def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tensor, padded: bool = False):
     """(k [n_ctx, L, C], vt [n_ctx, C, Lp]) of the distinct contexts ``ctx`` derived from the caller's tensor ``ehs``
-    (``idx`` = frame -> context map or None), from the cache or projected now; None where caching does not apply."""
+    (``idx`` = frame -> context map or None), from the cache or projected now; None where caching does not apply.
+    ``padded`` (every mode but INNER, whose interpolated keys are laid out compactly): rows / columns up to the next multiple of
+    64 keys, zero beyond L — the layout the short-stream ping-pong kernel reads (``AidProcessorArgs.kv_cached_lt``)."""
     if not TEXT_KV_CACHE or ehs is None or not torch.is_tensor(ehs):
         return None
     ks = (_vkey(ehs), _vkey(wk), _vkey(wv))
     if None in ks:
         return None
-    key = ks + (tuple(ehs.shape), ehs.dtype, tuple(idx) if idx is not None else None)
+    key = ks + (tuple(ehs.shape), ehs.dtype, tuple(idx) if idx is not None else None, bool(padded))
     try:
         per = _KV_CACHE.get(attn)
         if per is None:
@@ -335,7 +346,7 @@ def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tens
         return None
     hit = per.get(key)
     if hit is None:
-        k, vt = ops.project_kv(ctx, wk, wv)
+        k, vt = ops.project_kv(ctx, wk, wv, padded=padded)
         for old in [kk for kk in per if kk[0][0] == key[0][0] and kk[3:] == key[3:]]:
             per.pop(old, None)            # the same tensor at an older version (or with replaced weights)
 
@@ -409,7 +420,7 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
         ctx2, ctx_map, idx2 = _shared_context(proc._ctx_cache, full_map, full, n + 2)
         y = ops.processor_fwd(x, ctx2, wq, wk, wv, wo, bo, attn.heads, mode=mode, fused=proc.is_fused, coef=coef,
                               begin=nctx, end=nctx + 1, ctx_map=ctx_map[:n], n_plain=proc.plain_tail,
-                              kv_cached=_text_kv(attn, full, ctx2, idx2, wk, wv))
+                              kv_cached=_text_kv(attn, full, ctx2, idx2, wk, wv, padded=mode != "inner" and _kv_padded_layout()))
         return _epilogue(attn, y, residual, shape4)
     if ctx is not None and ctx_index is not None:
         ctx, ctx_map, idx = _shared_context(proc._ctx_cache, ctx_index, ctx, x.shape[0])
@@ -422,7 +433,7 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
                           begin=begin, end=end, ctx_map=ctx_map,
                           n_plain=proc.plain_tail if mode != "plain" else 0, ln=ln, residual=add_to, ln_folded=ln_folded,
                           seg_executed=ops.executed_segments(mode, fused, vals, x.shape[0], idx, begin, end),
-                          kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv) if ctx is not None else None)
+                          kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv, padded=mode != "inner" and _kv_padded_layout()) if ctx is not None else None)
     return _epilogue(attn, y, residual, shape4)
 
 
@@ -449,7 +460,8 @@ class HipAttnProcessor:
             ctx = ctx.contiguous()
         return ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map,
                                  ln=_ln_of(norm), residual=x, ln_folded=_ln_folded(attn, norm, ctx is not None),
-                                 kv_cached=_text_kv(attn, encoder_hidden_states, ctx, idx, wk, wv) if ctx is not None else None)
+                                 kv_cached=_text_kv(attn, encoder_hidden_states, ctx, idx, wk, wv, padded=_kv_padded_layout())
+                                 if ctx is not None else None)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  *args, ctx_index=None, **kwargs):
@@ -463,7 +475,7 @@ class HipAttnProcessor:
         elif ctx is not None:
             ctx = ctx.contiguous()
         y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map,
-                              kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv) if ctx is not None else None)
+                              kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv, padded=_kv_padded_layout()) if ctx is not None else None)
         return _epilogue(attn, y, residual, shape4)
 
 

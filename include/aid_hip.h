@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AID_ABI_VERSION 5
+#define AID_ABI_VERSION 6
 
 /* element types of activations / weights (accumulation is always fp32) */
 #define AID_DTYPE_F16  0
@@ -175,7 +175,10 @@ typedef struct AidAttnArgs {
     int32_t seg_executed;        /* profiling accounting: (frame, key segment) passes this launch really runs —  */
                                  /* fused END-POINT frames and coefficient-0/1 sides run fewer than the          */
                                  /* algorithmic count; 0 = unknown (reported equal to the algorithmic count)     */
-    int32_t reserved0;
+    int32_t kv_padded;           /* 1: every row of k holds at least round_up(l, 64) key rows (k_fs >= that * ldk) and every row   */
+                                 /* of vt at least round_up(l, 64) columns (ldvt >= that); key rows l .. are FINITE, value columns */
+                                 /* l .. are ZERO.  Lets short key streams (text cross-attention, l = 77) run on the ping-pong    */
+                                 /* kernel for short streams (csrc/aid_attn_xs.hip); 0: no such guarantee (ABI v6; was reserved0)  */
 } AidAttnArgs;
 
 int aid_attn_fwd(const AidAttnArgs* args /* host */, void* stream);
@@ -247,7 +250,10 @@ typedef struct AidProcessorArgs {
     float   ip_scale;
     int32_t ip_begin, ip_end;    /* AID_IP_SAME: image rows of the end-point frames           */
     int32_t seg_executed;        /* accounting, see AidAttnArgs.seg_executed (text launch only) */
-    int32_t reserved0;
+    int32_t kv_cached_lt;        /* layout of k_cached / vt_cached.  0: compact — k_cached [n_ctx, l, c], vt_cached [n_ctx, c, lp]  */
+                                 /* (lp = l rounded up to 8).  > 0: PADDED to whole key tiles — k_cached [n_ctx, lt, c], vt_cached  */
+                                 /* [n_ctx, c, lt] with lt = kv_cached_lt >= round_up(l, 64), key rows l .. lt finite, value        */
+                                 /* columns l .. lt ZERO (AidAttnArgs.kv_padded; ABI v6, was reserved0).  Not with AID_MODE_INNER.  */
     /* ---- folded LayerNorm (ln_eps > 0 and ln_wq != NULL): the call runs aid_ln_stats on x instead of aid_layernorm and  */
     /* projects x with the folded weights (aid_ln_fold of wq / wk / wv with ln_gamma / ln_beta; wk / wv only for           */
     /* self-attention, a cross-attention ctx is not normalised).  ln_const: fp32 [6, c] = colsum_q, shift_q, colsum_k,     */

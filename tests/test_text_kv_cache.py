@@ -16,7 +16,7 @@ class _Attn:                                # weakly referenceable stand-in for 
 
 
 def _fake_project(calls):
-    def project_kv(ctx, wk, wv, extra_rows=0):
+    def project_kv(ctx, wk, wv, extra_rows=0, padded=False):
         calls.append(tuple(ctx.shape))
         return ctx.clone(), ctx.clone()
     return project_kv
@@ -107,7 +107,12 @@ def test_cached_call_equals_uncached_call_and_oracle(dtype, kind, monkeypatch):
     y_hit = proc(attn, x, encoder_hidden_states=ctx)                        # query projection only
     assert len(P._KV_CACHE[attn]) == 1
     assert torch.equal(y_miss, y_hit)
-    assert torch.equal(y_hit, y_off), "the cached keys / values are the same numbers the grouped launch computes"
+    # the cached keys / values are the same numbers the grouped launch computes; with d = 64 the cached (tile-padded) layout runs on
+    # the short-stream ping-pong kernel, the per-call projection on aid_attn_kernel: same arithmetic, different summation order
+    if kind == "inner":
+        assert torch.equal(y_hit, y_off)
+    else:
+        assert rel_l2(to_np64(y_hit), to_np64(y_off)) < 0.5 * TOL[dtype]
     # an in-place edit of the context is seen (no stale keys), and the result is right
     with torch.no_grad():
         ctx.mul_(-0.5)
