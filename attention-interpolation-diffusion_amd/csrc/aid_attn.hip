@@ -1016,6 +1016,50 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     }
 
     // ---- epilogue: lane (q = l31, hi) holds dv = 32 d + 8 g + 4 hi + {0..3} ------------------------
+    // Streaming variants with one q block per wave: the wave's 32 x D block leaves through LDS (the tile buffers, free behind a
+    // barrier) as 16-byte stores covering whole rows of the head — 8-byte stores per lane at a row stride are store-ISSUE bound (the
+    // guide's T21; profiles/r04_attn_notes.txt): the 77-key launches, little more than a store tail, -9 ... -18 %.
+    constexpr bool STAGED = !RES && QB == 1 && D % 8 == 0 && (size_t)NBUF * (KT * KLD + DV * VLD) * sizeof(T) >= (size_t)NW * 32 * D * sizeof(T);
+    const bool staged = STAGED && a.ldo % 8 == 0 && a.o_fs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                        (int64_t)a.n_frames * a.o_fs * 2 < (1ll << 31);
+    if (STAGED && staged) {
+        __syncthreads();                                        // every wave is done with the K / V^T tiles
+        if (q0 < a.s) {
+            constexpr int RBY = D * 2, CPR = D / 8;             // bytes / 16-byte chunks per staged row
+            constexpr bool SWZ = CPR == 8;                      // d = 64: chunk c of row r at slot c ^ swz(r) (conflict-free read-back)
+            const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
+            char* const stg = smem_raw + wave * (32 * RBY);
+            const int wsw = SWZ ? (l31 >> 1) & 7 : 0;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dv = 32 * d + 8 * g + 4 * hi;
+                    if (32 * d + 8 * g < D) {                   // (compile-time: D is a multiple of 8, both halves of a chunk exist)
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = res[0][d][4 * g + e] * osc;
+                        *reinterpret_cast<T4*>(stg + l31 * RBY + (((dv >> 3) ^ wsw) << 4) + 8 * hi) = cvt4<T>(v);
+                    }
+                }
+            typedef __amdgpu_buffer_rsrc_t ORsrc;
+            const ORsrc ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0x7fffffff, 0x00020000);
+            const int so = (int)(((int64_t)fr * a.o_fs + h * D) * 2);
+            constexpr int NPASS = (32 * CPR + 63) / 64;
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int id = lane + 64 * i;
+                const int row = id / CPR, cc = id - row * CPR;
+                if (32 * CPR % 64 == 0 || id < 32 * CPR) {
+                    T8 v = *reinterpret_cast<const T8*>(stg + row * RBY + ((SWZ ? cc ^ ((row >> 1) & 7) : cc) << 4));
+                    const int q = q0 + row;
+                    const int vo = (min(q, a.s - 1) * a.ldo + cc * 8) * 2;
+                    if (a.accumulate) v = cvt8<T>(up8<T>(v) + up8<T>(__builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(ro, vo, so, 0))));
+                    if (q < a.s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, so, 0);
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         const int q = q0 + 32 * j + l31;
