@@ -114,7 +114,7 @@ def main():
         return
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     wls = sys.argv[sys.argv.index("--workloads") + 1].split(",") if "--workloads" in sys.argv else ["sdxl", "sd15"]
-    out = argv[0] if argv else os.path.join(ROOT, "profiles", "r03_pmc.json")
+    out = argv[0] if argv else os.path.join(ROOT, "profiles", "r04_pmc.json")
     res = {"_comment": __doc__.split("usage")[0].strip(), "models": {}}
     for wl in wls:
         merged = collections.defaultdict(dict)

@@ -1,9 +1,9 @@
-# Re-create the round's measurement set on the GPU box (run from the repo root under gpurun); results land in gpurun_out/r03/
-# and are copied to profiles/r03_* after review:  bench lines, rocprofv3 kernel-trace summaries of the SAME commands, the PMC
+# Re-create the round's measurement set on the GPU box (run from the repo root under gpurun); results land in gpurun_out/r04/
+# and are copied to profiles/r04_* after review:  bench lines, rocprofv3 kernel-trace summaries of the SAME commands, the PMC
 # collection (tools/pmc_collect.py), the per-launch breakdown of both stacks, the projection microbenchmark, the attention
 # A/B table of the knobs that decide the variants, the sublayer modes.
 set -x
-R=gpurun_out/r03; mkdir -p $R
+R=gpurun_out/r04; mkdir -p $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $R/bench_default.json 2> $R/bench_default.err
 timeout 400 python bench.py --workload ip --steps 20 --warmup 5 > $R/bench_ip.json 2> $R/bench_ip.err
 timeout 400 python bench.py --workload seq16 --steps 20 --warmup 5 --no-cpu-baseline > $R/bench_seq16.json 2> $R/bench_seq16.err
@@ -17,6 +17,8 @@ done
 cd $GRAFT_REPO_ROOT
 for w in sdxl sd15; do python tools/stack_breakdown.py $w > $R/breakdown_$w.txt 2>/dev/null; done
 python tools/kbench_proj.py > $R/kbench_proj.txt 2>/dev/null
+python tools/kbench_attn_ab.py "ATTN_V2=-1" "ATTN_V2=0" --rounds 5 --iters 6 --shapes sdxl --inner > $R/kbench_attn.txt 2>/dev/null
+python tools/dev/xs_ab.py > $R/xs_ab.txt 2>/dev/null
 python tools/gemm_ab.py "GEMM_TRI=0,GEMM_PP=0" "GEMM_TRI=0,GEMM_PP=1" "GEMM_TRI=-1,GEMM_PP=1" --rounds 5 --iters 10 --torch > $R/gemm_ab.txt 2>/dev/null
 for u in mfma_cadence store_bw valu_rate; do
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip
