@@ -100,3 +100,37 @@ def test_endpoint_exchange_layout_equals_replicated_layout(kind, cross):
         inner.endpoint_ctx = torch.stack([ctx[0], ctx[-1]])
     yi = inner(attn, x[1:-1].contiguous(), encoder_hidden_states=None if ctx is None else ctx[1:-1].contiguous())
     assert rel_l2(to_np64(yi), ref[1:-1]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("endpoints", ["replicate", "exchange"])
+@pytest.mark.parametrize("workload", ["sd15", "seq16"])
+def test_bench_two_ranks_on_one_device(endpoints, workload):
+    """`bench.py --gpus 2 --endpoints replicate|exchange` end to end: two rank processes on
+    cuda:0 (AID_BENCH_ONE_DEVICE=1: gloo collectives, the device code path unchanged) — frame sharding, the conditioning
+    broadcast, the per-layer end-point hand-over of the exchange layout, the all_gather of the owned frames and the
+    max-over-ranks timing all run, and rank 0 prints ONE JSON line carrying the contract's keys.  The 8-GPU RCCL run
+    itself is the driver's; this keeps the N > 1 bench path from rotting between rounds."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AID_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+           "--min-seconds", "0", "--workload", workload, "--endpoints", endpoints,
+           "--no-cpu-baseline", "--no-roofline", "--no-also"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["ms_per_step"] > 0
+    assert rec["metric"] == "interpolation-frames/sec (50-step)" and rec["unit"] == "frames/s"
+    assert rec["scaling"] == "strong" and rec["higher_is_better"] is True and rec["vs_baseline"] is None
+    cfg = rec["config"]
+    assert cfg["ranks"] == 2 and cfg["backend"] == "gloo" and "parity_tolerance" in cfg
+    assert ("replicated end points" in cfg["parallelism"]) == (endpoints == "replicate")
+    n = cfg["frames"]
+    assert n == (16 if workload == "seq16" else 7)
+    # replicate: ceil(interior / 2) owned + the 2 end points; exchange: owned frames only
+    assert cfg["max_local_batch"] == ((n - 2 + 1) // 2 + 2 if endpoints == "replicate" else (n + 1) // 2)

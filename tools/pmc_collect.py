@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Collect rocprofv3 PMC counters per launch of every aid_* kernel of the bench workloads -> profiles/r03_pmc.json.
+"""Collect rocprofv3 PMC counters per launch of every aid_* kernel of the bench workloads -> profiles/r04_pmc.json.
 
 Procedure (MI355X_MICROARCH.md, HBM / PMC-slot sections): every counter group is its OWN rocprofv3 pass with
 --kernel-trace only (never combined with sys / hip / memory-copy tracing), over
