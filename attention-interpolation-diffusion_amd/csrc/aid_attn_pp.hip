@@ -90,6 +90,12 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     typedef typename Vec<T>::v4 T4;
     constexpr int D = 64;
     constexpr float XTH = std::is_same<T, f16>::value ? 15.0f : 60.0f;      // head-room (log2) of P = 2^x in the storage type
+    // bf16 (SUMM): P is kept 2^-XB below "1 at the row reference", so that P >= 2 — bit 14 of a bf16, the top exponent bit — IS the
+    // head-room test (2^(XB + 1) above the reference); O and the row sums carry the same factor, which the quotient drops.  f16 has
+    // no exponent range to spare for the bias (and its PV product would meet subnormal P): it keeps the row-sum test.
+    constexpr bool SUMM = std::is_same<T, bf16>::value;
+    constexpr float XB = SUMM ? XTH - 1.f : 0.f;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
 #ifdef AID_ABLATIONS
@@ -321,6 +327,15 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     bool fresh = true;
     f32x16 o[2], sc[2];
     float lsum = 0.f;                   // row sum of the ROUNDED P over the 32 keys per tile this lane holds (the partner lane has the others)
+    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};  // SUMM: the same sum as the D block of the 4x4x4 MFMAs (four equal copies; lsum unused)
+    s16x4 ones4;                        // SUMM: A operand of those MFMAs, 4 x 4 ones per block
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ones4[i] = 0x3f80;
+    asm volatile("" : "+v"(ones4));
+    auto get_l = [&]() __attribute__((always_inline)) -> float { return SUMM ? lacc[0] : lsum; };
+    auto set_l = [&](float x) __attribute__((always_inline)) {
+        if (SUMM) { lacc[0] = x; lacc[1] = x; lacc[2] = x; lacc[3] = x; } else lsum = x;
+    };
     T8 pf[4];
     f32x16 cneg;                        // -m as an accumulator block (C operand of a tile's first score MFMAs), rebuilt when m moves
     f32x16 po[2];                       // parked: O of the own-keys state while the begin side runs, then the finished begin side
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 #ifdef AID_ABLATIONS
     // 16: slot timing — shader cycles of [V work | wait at the barrier behind it | M work | wait at the barrier behind it], summed over the
     // tiles and written over the output rows (lane 0 of every wave: four floats = cycles per tile)
-    long long tmark = 0;
+    long long tmark = clock64();
     float tacc[4] = {0.f, 0.f, 0.f, 0.f};
     auto stamp = [&](int which) __attribute__((always_inline)) {
         if (p.abl & 16) {
@@ -354,6 +369,23 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 #define PP_STAMP(i)
 #endif
 
+    // MFMA results and the VALU code that reads them.  The hazard recogniser does not see across the slots' barriers / branches
+    // (aid_attn.hip has the history), so the distance is kept by hand: an 8-pass MFMA's result may be read 11 wait states (of four
+    // cycles) after its issue.  `sc` is read by the next V slot — behind the eight PV MFMAs that follow the score MFMAs in every M slot
+    // and a barrier (>= 48 cycles): no padding needed in the loop, only the compiler is told not to move anything across (tie).
+    // `o` / the row-sum block are read by the rare paths only (raise, park, swap_sides, finish): THEY start with the padding (settle)
+    // — 20 wait states per M slot were 76 cycles of every 1120-cycle interval (tools/ubench/barrier_cost.hip).  The prologue's S(0)
+    // has nothing behind it and is settled as before.
+    auto tie = [&]() __attribute__((always_inline)) {
+        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]));
+        if (SUMM) asm volatile("" : "+v"(lacc));
+    };
+    auto settle = [&]() __attribute__((always_inline)) {
+        tie();
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        tie();
+    };
     // operand fragments: kf = K(t + 1) for S(t + 1), vf = V^T(t) for O += V^T(t) P(t)^T, all four k-steps each
     T8 kf[4][2], vf[4][2];
     auto lds_k = [&](int st, int ks, int b) __attribute__((always_inline)) {           // st: ring stage, a constant wherever it matters
@@ -378,6 +410,9 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ks = i >> 1, b = i & 1;
+#ifdef AID_ABLATIONS
+            if (!((p.abl & 64) && b))                           // 64: half the fragment reads (is the M slot bound by the LDS port?)
+#endif
             vf[ks][b] = lds_v(sv, ks, b);
             pin();
             sc[b] = mfma32(kf[ks][b], qf[ks], ks ? sc[b] : cneg);
@@ -388,13 +423,26 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             const int kk = i >> 1, w = i & 1;
             o[w] = mfma32(vf[kk][w], pf[kk], o[w]);
             pin();
+            if constexpr (SUMM) {                               // l += the lane's four P values of half w of k-step kk (D[i][j] = sum_k B[k][j])
+                const u32x4 w4 = __builtin_bit_cast(u32x4, pf[kk]);
+                u32x2 h2;
+                h2[0] = w4[2 * w]; h2[1] = w4[2 * w + 1];
+                lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, h2), lacc, 0, 0, 0);
+                pin();
+            }
+#ifdef AID_ABLATIONS
+            if (!((p.abl & 64) && w))
+#endif
             kf[kk][w] = lds_k(sk, kk, w);                       // (kf[kk][w] was released by score MFMA 2 kk + w, eight or more MFMAs ago)
             pin();
         }
     };
 
     // V slot: P(t) = 2^S(t) (row reference raised first when the head-room of the storage type is exceeded), rounded to the storage
-    // type; this wave's two DMA pieces of tile t + LEAD; the counted wait that retires its pieces of tile t + 3
+    // type; this wave's two DMA pieces of tile t + LEAD; the counted wait that retires its pieces of tile t + 3.
+    // bf16: 32 v_exp + 16 v_cvt_pk + 8 v_or3 / v_bitop3 + 1 compare — the row sums are the M slot's (eight 4x4x4 MFMAs of 8 cycles behind
+    // the PV MFMAs; 16 v_dot2c + 2 v_mov + 2 v_add less here: -0.4 ... -4 % per launch, profiles/r04_attn_notes.txt table 5).
+    // (The requests stay HERE: issued from the M slot they cost 3 - 18 %, table 4.)
     constexpr int LEAD = 6;
     auto vslot = [&](int t) __attribute__((always_inline)) {
         // The DMA stream never stops: behind the workgroup's last item it wraps into that item's first segment again (valid memory,
@@ -429,6 +477,23 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 }
             return t0 + t1;
         };
+        // SUMM: the same without the sums — they are formed from pf in the M slot — returning the OR of the 16 packed words instead
+        // (v_or3_b32): a value >= 2 anywhere shows in bit 14 of one of its halves (P >= 0: no other value has that bit)
+        auto exp_tile_or = [&]() __attribute__((always_inline)) -> uint32_t {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x8 pv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sc[b][8 * u + e]);
+                    pf[2 * b + u] = cvt8<T>(pv);
+                    const u32x4 w4 = __builtin_bit_cast(u32x4, pf[2 * b + u]);
+                    acc = (b == 0 && u == 0) ? (w4[0] | w4[1] | w4[2]) | w4[3] : (acc | w4[0] | w4[1]) | (w4[2] | w4[3]);
+                }
+            return acc;
+        };
         auto row_max = [&]() __attribute__((always_inline)) -> float {
             float xm = fmaxf(sc[0][0], sc[0][1]);
 #ifdef AID_ABLATIONS
@@ -441,7 +506,8 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         // slow path (first tile of the row, or a score out-grew the head-room of the storage type): move the reference to the row
         // maximum, rescale O and l and shift this tile's arguments; PV(t - 1) is complete, O is at rest
         auto raise = [&](float xm) __attribute__((always_inline)) {
-            const float rowmax = max_halves(xm);
+            settle();
+            const float rowmax = max_halves(xm) + XB;           // (SUMM: the row maximum lands at -XB)
             const float shift = fresh ? rowmax : fmaxf(rowmax, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-shift);
             m += shift;
@@ -450,7 +516,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
             asm volatile("" : "+v"(cneg));                      // (opaque: keeps hipcc from rebuilding the block in every M slot)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-            lsum *= alpha;
+            if (SUMM) lacc *= alpha; else lsum *= alpha;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -461,25 +527,36 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         // the head-room (sum of this lane's 32 values above 2^XTH; an f32 / storage-type overflow arrives as +inf and tests true as well)
         // is simply redone against the raised reference.  The sixteen v_max3 of a per-tile maximum chain become one compare:
         // -2.7 ... -3.1 % per launch (profiles/r04_attn_notes.txt); every P that reaches the PV product is <= 2^XTH as before.
-        float ts = fresh ? 0.f : exp_tile();
-        if (fresh || __any(ts > __builtin_amdgcn_exp2f(XTH))) {
-            raise(row_max());
-            ts = exp_tile();
+        if constexpr (SUMM) {
+            const uint32_t orw = fresh ? 0u : exp_tile_or();
+            if (fresh || __any((orw & 0x40004000u) != 0u)) {
+                raise(row_max());
+                exp_tile_or();
+            }
+        } else {
+            float ts = fresh ? 0.f : exp_tile();
+            if (fresh || __any(ts > __builtin_amdgcn_exp2f(XTH))) {
+                raise(row_max());
+                ts = exp_tile();
+            }
+            lsum += ts;
         }
-        lsum += ts;
         wait_vm<6>();                                           // retires tile t + 3: the three tiles behind it stay in flight
     };
 
     // Segment boundaries of a two-sided frame.  S(t) of the next segment's first tile is in `sc` and PV(t - 1) closed the segment
     // before it: O, l, m are at rest.
     auto park = [&]() __attribute__((always_inline)) {          // own keys done: park the state, the begin side continues on it
+        settle();
 #pragma unroll
         for (int r = 0; r < 16; ++r) { po[0][r] = o[0][r]; po[1][r] = o[1][r]; }
-        pl = lsum;
+        pl = get_l();
         pm = m;
     };
     auto swap_sides = [&]() __attribute__((always_inline)) {    // begin side done: keep (1 - c) O_b / l_b, resume the own-keys state
-        const float lrow = lsum + other_half(lsum);             // (all lanes take part in the exchange)
+        settle();
+        const float lown = get_l();
+        const float lrow = lown + other_half(lown);             // (all lanes take part in the exchange)
         const float wb = w_b / lrow;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -489,7 +566,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 o[d][r] = po[d][r];
                 po[d][r] = rb;
             }
-        lsum = pl;
+        set_l(pl);
         const float back = m - pm;                              // S(t) was formed against the begin side's reference (>= the parked one)
         m = pm;
 #pragma unroll
@@ -507,17 +584,21 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // item after that only at the top of the next item) and leaves as four 16-byte stores per lane covering whole 128-byte rows: eight
     // 8-byte stores per lane at a row stride are store-ISSUE bound (~1.4 us per item measured on the short-stream kernel; the guide's T21).
     auto finish = [&]() __attribute__((always_inline)) {
+        settle();
 #ifdef AID_ABLATIONS
         if (p.abl & (16 | 32)) {                                // slot timing / workgroup timeline instead of the result
             if (lane == 0 && q0 < a.s) {
                 float* dbg = reinterpret_cast<float*>(reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + (int64_t)q0 * a.ldo + h * D);
-                if (p.abl & 16) for (int i = 0; i < 4; ++i) dbg[i] = tacc[i] / (float)(NT - 1);
+                if (p.abl & 16) for (int i = 0; i < 4; ++i) dbg[i] = tacc[i] / (float)NT;
                 else { tl[4] = clock64(); for (int i = 1; i < 5; ++i) dbg[i - 1] = (float)(tl[i] - tl[0]); }
             }
+            for (int i = 0; i < 4; ++i) tacc[i] = 0.f;          // per item; the item boundary itself is not in the slots
+            tmark = clock64();
             return;
         }
 #endif
-        const float inv = w_e / (lsum + other_half(lsum));      // (w_e = 1 unless this frame mixes two sides)
+        const float lown = get_l();
+        const float inv = w_e / (lown + other_half(lown));      // (w_e = 1 unless this frame mixes two sides)
         if (q0 >= a.s) return;                                  // (wave-uniform: a wave past the last row)
         const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
         if (MODE == AID_MODE_OUTER) {
@@ -565,16 +646,6 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 if (q < a.s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, so, 0);
             }
         }
-    };
-
-    // fence between a slot's last MFMAs and the VALU code of the next slot that reads their results (20 wait states; the hazard
-    // recogniser does not see across the barrier's asm / branches — aid_attn.hip has the history)
-    auto settle = [&]() __attribute__((always_inline)) {
-        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
-        asm volatile("" : "+v"(o[0]), "+v"(o[1]));
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
-        asm volatile("" : "+v"(o[0]), "+v"(o[1]));
     };
 
     // Schedule.  Group g runs M(t) in interval 2 t + g and V(t) in 2 t + 1 + g (M(t) computes S(t) and the PV product of tile t - 1).
@@ -656,7 +727,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                     slot_barrier();
                     PP_STAMP(1);
                     mslot(i, (i + 2) & 7);
-                    settle();
+                    tie();
                     PP_STAMP(2);
                     slot_barrier();
                 }
@@ -666,7 +737,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         if (!has_next) break;
         // the next item: its S(0) is in `sc`; everything else starts over
         fresh = true;
-        lsum = 0.f;
+        set_l(0.f);
         pl = 0.f;
         pm = 0.f;
 #pragma unroll

