@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         }
         dk += kstep;
         dv += PKT * 2;
-        if (--dleft == 0) {                                     // next segment (arithmetic on values, see above)
+        if (__builtin_expect(--dleft == 0, 0)) {                // next segment (arithmetic on values, see above)
             ++dseg;
             dleft = nt;
             if (dseg < nseg) {
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
     // the PV MFMAs; 16 v_dot2c + 2 v_mov + 2 v_add less here: -0.4 ... -4 % per launch, profiles/r04_attn_notes.txt table 5).
     // (The requests stay HERE: issued from the M slot they cost 3 - 18 %, table 4.)
     constexpr int LEAD = 6;
-    auto vslot = [&](int t) __attribute__((always_inline)) {
+    auto vslot = [&](int t, bool first) __attribute__((always_inline)) {
         // The DMA stream never stops: behind the workgroup's last item it wraps into that item's first segment again (valid memory,
         // nobody reads those stages), so the slot has no "is there a tile t + LEAD" branch and ONE counted wait — the tail logic cost
         // 1.6 % (plain) to 6 % (inner) of the launch (profiles/r04_attn_notes.txt).
@@ -527,15 +527,18 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
         // the head-room (sum of this lane's 32 values above 2^XTH; an f32 / storage-type overflow arrives as +inf and tests true as well)
         // is simply redone against the raised reference.  The sixteen v_max3 of a per-tile maximum chain become one compare:
         // -2.7 ... -3.1 % per launch (profiles/r04_attn_notes.txt); every P that reaches the PV product is <= 2^XTH as before.
+        // (`fresh` is set where an item or a pure OUTER side starts: tile 0 of a trip.  `first` is a constant in each unrolled copy,
+        //  so seven of eight copies carry no test of it; the unlikely paths sit out of line: two taken branches less per slot, -1.4 ... -3.8 %)
+        const bool fr = first && fresh;
         if constexpr (SUMM) {
-            const uint32_t orw = fresh ? 0u : exp_tile_or();
-            if (fresh || __any((orw & 0x40004000u) != 0u)) {
+            const uint32_t orw = fr ? 0u : exp_tile_or();
+            if (__builtin_expect(fr || __any((orw & 0x40004000u) != 0u), 0)) {
                 raise(row_max());
                 exp_tile_or();
             }
         } else {
-            float ts = fresh ? 0.f : exp_tile();
-            if (fresh || __any(ts > __builtin_amdgcn_exp2f(XTH))) {
+            float ts = fr ? 0.f : exp_tile();
+            if (__builtin_expect(fr || __any(ts > __builtin_amdgcn_exp2f(XTH)), 0)) {
                 raise(row_max());
                 ts = exp_tile();
             }
@@ -713,8 +716,8 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                     const int t = t8 + i;
                     if (t >= t_end) break;
                     PP_STAMP(3);
-                    vslot(t);
-                    if (has_next && t == NT - 1) {              // the M slot behind the item's last tile forms the next item's S(0):
+                    vslot(t, i == 0);
+                    if (i == 7 && __builtin_expect(has_next && t == NT - 1, 0)) {   // (items with a successor are whole trips) the M slot behind the item's last tile forms the next item's S(0):
 #pragma unroll                                                  // its Q rows, and a zero row reference like a fresh workgroup's
                         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const T8*>(qlds + ks * 1024 + lane * 16);
                         scale_q();
