@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     if (!need) st.fresh = false;
                 }
             }
-            if (need) {
+            if (__builtin_expect(need, 0)) {                    // (out of line: the fast path falls through)
                 // slow path (first tile of a row, or a score out-grew the head-room): move the reference to the
                 // row maximum, rescale O (its ones-row = l included) and shift this tile's arguments in registers
                 st.mz = false;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                 float mall = mx[0];
 #pragma unroll
                 for (int j = 1; j < QB; ++j) mall = fmaxf(mall, mx[j]);
-                if (st.fresh || __any(mall > XTH)) slow(i, s_cur);
+                if (__builtin_expect(st.fresh || __any(mall > XTH), 0)) slow(i, s_cur);
                 __builtin_amdgcn_sched_barrier(0);
                 // ---------------- phase B ----------------
                 if (HAS_QK) {
