@@ -1,16 +1,18 @@
 // Ping-pong attention core for head dim 64 and whole 64-key tiles — plain attention (de-activated passes, reference
 // interpolation.py:581-584), the PLAIN riders of a batched-CFG call, and the interpolated frames of INNER / OUTER calls
 // (interpolation.py:626-664, 760-790) as ONE tile stream over the frame's key segments.  Same arithmetic as aid_attn_kernel (swapped
-// products, -m folded into the score MFMAs' accumulator, lazy row reference; the row sums here are VALU dot products of the rounded P,
-// not a ones-row block); what differs is WHO does what WHEN:
+// products, -m folded into the score MFMAs' accumulator, lazy row reference; the row sums here are sums of the ROUNDED P — bf16: eight
+// 4x4x4 MFMAs against a ones operand behind the PV MFMAs, f16: v_dot2c in the V slot — not a ones-row block); what differs is WHO does
+// what WHEN:
 //
 //   One workgroup = 8 waves x 32 query rows of one (frame, head); waves w and w + 4 share a SIMD.  Waves 0-3 and waves 4-7
 //   run the same program ONE BARRIER APART, and the program alternates two slots per 64-key tile:
 //     M(t)   every MFMA of the tile in one burst: S(t) = K(t) Q'^T - m (8), then O^T += V^T(t-1) P(t-1)^T (8); in their shadow,
 //            one per MFMA and in pinned program order, the 16 operand-fragment reads: V^T(t-1) beside the score MFMAs, K(t+1)
-//            beside the PV MFMAs into the registers the score MFMAs released.  No VALU instruction.
-//     V(t)   the VALU half: P(t) = 2^S(t), rounding to the storage type, row sums (v_dot2c), head-room test on the row sum; plus this wave's two
-//            LDS-DMA pieces of tile t + 6 and the counted wait that retires its pieces of tile t + 3
+//            beside the PV MFMAs into the registers the score MFMAs released (bf16: + the eight row-sum MFMAs).  No VALU instruction.
+//     V(t)   the VALU half: P(t) = 2^S(t), rounding to the storage type, the head-room test (bf16: on the exponent bits of the packed P,
+//            f16: on the tile's row sum, formed here with v_dot2c); plus this wave's two LDS-DMA pieces of tile t + 6 and the counted
+//            wait that retires its pieces of tile t + 3
 //   so while one wave of a SIMD keeps the matrix pipe busy its partner does the exponentials, and vice versa.  In the
 //   program-order kernel the three co-resident waves of a SIMD drift into the same phase and MFMA time and VALU time add up
 //   (1100 cycles per wave-tile for 640 of MFMA, profiles/r02_attn_notes.txt); here they are complementary by construction.
@@ -23,7 +25,9 @@
 // Measured (profiles/r03_attn_notes.txt, same process): S = 4096 plain 597 us against 658 for the program-order kernel, fused outer
 // 1089 against 1213, fused inner 838 against 943; S = 1024 plain 107 against 95 (a 16-tile stream on one workgroup per CU).
 // Round 4 (profiles/r04_attn_notes.txt): one instantiation per call mode, a DMA stream that never stops (no tail branches in the V
-// slot), head-room test on the row sum instead of a maximum chain: plain -4.2 %, outer -4.6 %, inner -5 % per launch.
+// slot), head-room test on the row sum instead of a maximum chain: plain -4.2 %, outer -4.6 %, inner -5 % per launch; balanced
+// persistent walk for every mode, staged stores; bf16 row sums on the matrix pipe + exponent-bit test, no padding in the loop,
+// straight-line fast path: S = 4096 plain 524 - 562 us by box, fused outer 880 - 965, S = 1024 fused outer 132 - 143.
 // aid_attn_fwd's default rule: fused OUTER / INNER from 1024 keys, everything else from 2048.
 #include <type_traits>
 
