@@ -74,6 +74,33 @@ def set_ctx_index(unet, ctx_index: Optional[Sequence[int]]) -> None:
             inner.ctx_index = idx
 
 
+def _record_stream(out, stream) -> None:
+    if torch.is_tensor(out):
+        out.record_stream(stream)
+    elif isinstance(out, dict):
+        for v in out.values():
+            _record_stream(v, stream)
+    elif isinstance(out, (tuple, list)):
+        for v in out:
+            _record_stream(v, stream)
+
+
+def fork_join(first: Callable, second: Callable, side: "torch.cuda.Stream"):
+    """``first()`` on the current stream and ``second()`` on ``side``, concurrently; both have finished (for the current stream) on
+    return.  Inside a stream capture the fork and the join become edges of the graph.  The two callables run one after the other on
+    the host, so Python-side state they toggle (``set_aid_active``) is seen in program order; what ``second`` returns was allocated on
+    ``side`` and is handed to the current stream (``record_stream``; captured allocations live in the graph's pool)."""
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    a = first()
+    with torch.cuda.stream(side):
+        b = second()
+    cur.wait_stream(side)
+    if not torch.cuda.is_current_stream_capturing():
+        _record_stream(b, cur)
+    return a, b
+
+
 class AidDenoiseLoop:
     """Replays the per-step attention work of an interpolation run.
 
@@ -83,7 +110,7 @@ class AidDenoiseLoop:
 
     def __init__(self, unet, sample, cond, uncond, num_inference_steps: int = 50, warmup_ratio: float = 0.5,
                  guidance_scale: float = 7.5, use_graphs: bool = True, combine: Optional[Callable] = None,
-                 batched_cfg: bool = False, ctx_index: Optional[Sequence[int]] = None):
+                 batched_cfg: bool = False, ctx_index: Optional[Sequence[int]] = None, concurrent_cfg: bool = False):
         """``batched_cfg``: run the conditional and the unconditional pass of a step as ONE UNet call over the
         batch [cond frames ; uncond frames] (how stock diffusers pipelines do classifier-free guidance).  The
         AID processors treat the second half as plain riders (negative coefficients), so the result equals the
@@ -92,8 +119,13 @@ class AidDenoiseLoop:
         prompt, sequence.py); ``cond`` / ``uncond`` then hold the DISTINCT contexts only."""
         """``cond`` / ``uncond`` may be ``(text, [image_embeds])`` tuples — the ``encoder_hidden_states`` an IP-Adapter UNet
         hands its attention layers (interpolation.py:259-266); the two passes then run as two UNet calls."""
+        """``concurrent_cfg``: when the two passes of a step cannot share one UNet call (IP-Adapter contexts), run them as two UNet
+        calls on two STREAMS — forked and joined inside one hipGraph when ``use_graphs`` — instead of back to back: the passes are
+        independent, every kernel of one overlaps the other's (half the rows per kernel, both halves in flight).  Same results."""
         self.unet, self.sample, self.cond, self.uncond = unet, sample, cond, uncond
         self.batched_cfg = batched_cfg
+        self.concurrent_cfg = concurrent_cfg and not batched_cfg
+        self._side = None
         first = next(iter(sample.values())) if isinstance(sample, dict) else sample
         self.n_frames = first.shape[0]
         self.ctx_index = None if ctx_index is None else [int(i) for i in ctx_index]
@@ -133,6 +165,18 @@ class AidDenoiseLoop:
         if which == "both_plain":
             set_aid_active(self.unet, False)
             return self.unet(self.sample2, self.ctx2)
+        if which.startswith("pair"):                    # cond pass on the current stream, uncond pass on the side stream
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+
+            def cond_pass():
+                set_aid_active(self.unet, which == "pair_aid", plain_tail=0)
+                return self.unet(self.sample, self.cond)
+
+            def uncond_pass():
+                set_aid_active(self.unet, False)
+                return self.unet(self.sample, self.uncond)
+            return fork_join(cond_pass, uncond_pass, self._side)
         if which == "cond_aid":
             set_aid_active(self.unet, True, plain_tail=0)
             return self.unet(self.sample, self.cond)
@@ -168,6 +212,9 @@ class AidDenoiseLoop:
             if isinstance(both, dict):
                 return self.combine({k: v[:n] for k, v in both.items()}, {k: v[n:] for k, v in both.items()})
             return self.combine(both[:n], both[n:])
+        if self.concurrent_cfg:
+            text, unc = self._run("pair_aid" if self.aid_on(i) else "pair_plain")
+            return self.combine(text, unc)
         text = self._run("cond_aid" if self.aid_on(i) else "cond_plain")
         unc = self._run("uncond")
         return self.combine(text, unc)

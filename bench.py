@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--separate-passes", action="store_true",
                     help="run the cond and the uncond pass as two UNet calls like the reference loop "
                          "(default: one call over [cond ; uncond], same work, same results)")
+    ap.add_argument("--serial-passes", action="store_true",
+                    help="ip: run the cond and the uncond UNet call back to back on one stream (default: on two streams inside one graph)")
     ap.add_argument("--guide-prompt", default="auto", choices=["auto", "on", "off"],
                     help="PAID: interior frames share the guide prompt's text context (3 distinct contexts)")
     ap.add_argument("--ip-tokens", type=int, default=4, help="ip: image tokens per frame (4: ImageProjection, 16: plus)")
@@ -344,7 +346,8 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
             p.endpoint_exchange, p.endpoint_ctx = ex, end_ctx
         args.no_graph = True                 # a collective per layer: eager launches
     loop = AidDenoiseLoop(unet, xs, cond, uncond, num_inference_steps=steps, warmup_ratio=args.warmup_ratio,
-                          use_graphs=not args.no_graph, batched_cfg=batched, ctx_index=ctx_index)
+                          use_graphs=not args.no_graph, batched_cfg=batched, ctx_index=ctx_index,
+                          concurrent_cfg=(name == "ip" and not args.serial_passes))
     return dict(name=name, stack=stack, dtype=dt, early=early, what=what, n_total=n_total, shard=shard, guided=guided,
                 unet=unet, loop=loop, batched=batched, gather_key=unet.level_shapes()[-1])
 
@@ -449,6 +452,7 @@ def main():
             "early": wl["early"], "late": "plain", "warmup_ratio": args.warmup_ratio,
             "aid_steps": loop.warmup_steps,
             "passes_per_step": ("cond + uncond (CFG) batched in one UNet call [cond ; uncond]" if wl["batched"]
+                                else "cond + uncond (CFG), two UNet calls on two streams (one graph)" if (name == "ip" and not args.serial_passes)
                                 else "cond + uncond (CFG), two UNet calls"),
             "contexts": ("PAID guide prompt: interior frames share one text context (3 distinct per pass), keys/values "
                          "projected once per distinct context" if wl["guided"] else "one text context per frame"),
