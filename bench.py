@@ -146,8 +146,9 @@ def recorded_traffic(stack, kernel):
 def roofline_pass(loop, aid_amd, torch):
     """HIP-event timing (on the launch stream) of every kernel of one AID step + one plain step."""
     lib = aid_amd._lib.load()
-    was = loop.use_graphs
+    was, was_conc = loop.use_graphs, getattr(loop, "concurrent_cfg", False)
     loop.use_graphs = False
+    loop.concurrent_cfg = False                                  # every kernel alone on the device: the two passes back to back
     loop.step(0); loop.step(loop.num_inference_steps - 1)        # eager warm-up
     torch.cuda.synchronize()
     lib.aid_profile_begin()
@@ -155,7 +156,7 @@ def roofline_pass(loop, aid_amd, torch):
     loop.step(loop.num_inference_steps - 1)                      # plain step
     buf = (aid_amd._lib.AidProfileEntry * 8192)()
     n = lib.aid_profile_end(buf, 8192)
-    loop.use_graphs = was
+    loop.use_graphs, loop.concurrent_cfg = was, was_conc
     if n < 0:
         raise RuntimeError(lib.aid_strerror(n).decode())
     agg = {}
