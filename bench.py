@@ -69,11 +69,13 @@ def parse():
     ap.add_argument("--warmup-ratio", type=float, default=0.5)
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K steps until the timed region is this long")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
-    ap.add_argument("--separate-passes", action="store_true",
-                    help="run the cond and the uncond pass as two UNet calls like the reference loop "
-                         "(default: one call over [cond ; uncond], same work, same results)")
-    ap.add_argument("--serial-passes", action="store_true",
-                    help="ip: run the cond and the uncond UNet call back to back on one stream (default: on two streams inside one graph)")
+    ap.add_argument("--passes", default="auto", choices=["auto", "batched", "streams", "serial"],
+                    help="the cond and the uncond pass of a step: ONE UNet call over [cond ; uncond] (batched; same work, same results "
+                         "as the reference's two calls) | two UNet calls on two streams, forked and joined inside one graph (streams) | "
+                         "two UNet calls back to back like the reference loop (serial).  auto: batched for the SDXL text workloads, "
+                         "streams for sd15 (its small launches do not fill the device: 5.66 -> 5.39 ms/step) and for ip (two different "
+                         "image embeddings cannot share a call)")
+    ap.add_argument("--separate-passes", action="store_true", help="alias of --passes serial")
     ap.add_argument("--guide-prompt", default="auto", choices=["auto", "on", "off"],
                     help="PAID: interior frames share the guide prompt's text context (3 distinct contexts)")
     ap.add_argument("--ip-tokens", type=int, default=4, help="ip: image tokens per frame (4: ImageProjection, 16: plus)")
@@ -328,7 +330,12 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
     sel = torch.tensor(used, device=device)
     cond, uncond = cond.index_select(0, sel).contiguous(), uncond.index_select(0, sel).contiguous()
     local_coef = coef[list(shard.index)]
-    batched = not args.separate_passes
+    passes = "serial" if args.separate_passes else args.passes
+    if passes == "auto":
+        passes = "streams" if (name in ("sd15", "ip") and not exch) else "batched"    # (exchange layout: collectives per layer, one stream)
+    if name == "ip" and passes == "batched":
+        raise SystemExit("--workload ip: the two passes carry different image embeddings (--passes streams | serial)")
+    batched = passes == "batched"
     if name == "ip":
         unet.load_ip_adapter(num_tokens=args.ip_tokens, scale=0.6)
         aid_amd.load_aid_ip_adapter(unet, t=None, size=shard.n_local, is_fused=True, early=early, alpha=steps, beta=steps)
@@ -336,7 +343,6 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
             p.coef = local_coef.detach().to(torch.float32).cpu().clone()
         rep3 = lambda t: adist.shard_rows(t, shard).repeat_interleave(3, dim=0).contiguous()      # noqa: E731
         cond, uncond = (cond, [rep3(ip_pos)]), (uncond, [rep3(ip_neg)])
-        batched = False                      # the two passes carry different image embeddings: two UNet calls, like the reference
     else:
         install_sequence_processors(unet, shard.n_local, early=early, num_inference_steps=steps, coef=local_coef)
     if exch:
@@ -348,9 +354,9 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
         args.no_graph = True                 # a collective per layer: eager launches
     loop = AidDenoiseLoop(unet, xs, cond, uncond, num_inference_steps=steps, warmup_ratio=args.warmup_ratio,
                           use_graphs=not args.no_graph, batched_cfg=batched, ctx_index=ctx_index,
-                          concurrent_cfg=(name == "ip" and not args.serial_passes))
+                          concurrent_cfg=(passes == "streams"))
     return dict(name=name, stack=stack, dtype=dt, early=early, what=what, n_total=n_total, shard=shard, guided=guided,
-                unet=unet, loop=loop, batched=batched, gather_key=unet.level_shapes()[-1])
+                unet=unet, loop=loop, batched=batched, passes=passes, gather_key=unet.level_shapes()[-1])
 
 
 def time_workload(wl, args, world, device, torch, dist):
@@ -452,9 +458,9 @@ def main():
             "frames": wl["n_total"], "local_batch": shard.n_local, "owned_frames": shard.n_owned,
             "early": wl["early"], "late": "plain", "warmup_ratio": args.warmup_ratio,
             "aid_steps": loop.warmup_steps,
-            "passes_per_step": ("cond + uncond (CFG) batched in one UNet call [cond ; uncond]" if wl["batched"]
-                                else "cond + uncond (CFG), two UNet calls on two streams (one graph)" if (name == "ip" and not args.serial_passes)
-                                else "cond + uncond (CFG), two UNet calls"),
+            "passes_per_step": {"batched": "cond + uncond (CFG) batched in one UNet call [cond ; uncond]",
+                                "streams": "cond + uncond (CFG), two UNet calls on two streams, forked and joined inside one graph",
+                                "serial": "cond + uncond (CFG), two UNet calls back to back"}[wl["passes"]],
             "contexts": ("PAID guide prompt: interior frames share one text context (3 distinct per pass), keys/values "
                          "projected once per distinct context" if wl["guided"] else "one text context per frame"),
             "sublayers": {"off": "attention calls only (the BASELINE metric)",
