@@ -60,7 +60,7 @@ def collect(workload, counters):
     out = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "2", "--no-graph",
-           "--no-cpu-baseline", "--no-roofline", "--no-also", "--min-seconds", "0"]
+           "--no-cpu-baseline", "--no-roofline", "--no-also", "--min-seconds", "0"] + (["--passes", "serial"] if workload in ("sd15", "ip") else [])
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
     f = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)[0]

@@ -10,7 +10,7 @@ timeout 400 python bench.py --workload seq16 --steps 20 --warmup 5 --no-cpu-base
 cd /tmp && export TMPDIR=/tmp
 for w in sdxl sd15; do
   rm -rf /tmp/prof_$w
-  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-also --min-seconds 0 > $GRAFT_REPO_ROOT/$R/${w}_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$R/${w}_rocprof.err
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-also --min-seconds 0 $([ $w = sd15 ] && echo --passes serial) > $GRAFT_REPO_ROOT/$R/${w}_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$R/${w}_rocprof.err
   db=$(find /tmp/prof_$w -name '*.db' | head -1)
   python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $db $GRAFT_REPO_ROOT/$R/${w}_kernel_stats.txt > /dev/null
 done

@@ -9,6 +9,8 @@ import aid_amd
 import bench
 name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "sdxl"
 sys.argv = [sys.argv[0], "--no-graph"] + [a for a in sys.argv[2:]]
+if "--passes" not in sys.argv and name in ("sd15", "ip"):
+    sys.argv += ["--passes", "serial"]            # the launches of the default (two-stream) form, each timed alone on the device
 args = bench.parse()
 dev = torch.device("cuda:0")
 wl = bench.build_workload(name, args, 1, 0, dev, torch, aid_amd)
