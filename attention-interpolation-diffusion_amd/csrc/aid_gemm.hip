@@ -1683,8 +1683,12 @@ static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char**
     }
     // development knob (tools/gemm_shapes.py): AID_GEMM_VARIANT=7 / 31 forces the lock-step / ping-pong engine
     const int force = tune(TUNE_GEMM_VARIANT);
-    const int ncu = num_cu();
+    int ncu = num_cu();
     if (ncu <= 0) return hipErrorInvalidDevice;
+    // CU_SHARE = n: n launch streams share the device (the two passes of a step on two streams): a launch can count on 1 / n of the
+    // CUs, so e.g. 125 tiles of 288 rows are a full round, not half of one (SDXL, two streams: 39.0 -> 37.3 ms/step)
+    const int share = tune(TUNE_CU_SHARE);
+    if (share > 1) ncu = (ncu / share + 7) / 8 * 8;
     bool pp = false;
     PpPlan pl = {};
     GemmSide sd;

@@ -59,6 +59,8 @@ enum Tune {
     TUNE_ATTN_RES_CHUNKS,       // > 0: chunks per (frame, head) of the resident variant
     TUNE_ATTN_ORDER,            // 0 = plain XCD order for mixed launches
     TUNE_ATTN_V2,               // ping-pong d = 64 kernel: 0 never / 1 wherever supported; default: fused OUTER l >= 1024, everything else l >= 2048
+    TUNE_CU_SHARE,              // n > 1: the caller runs n independent launch streams side by side (two passes on two streams): the GEMM
+                                // engine choice plans with 1 / n of the CUs; a hint, results never depend on it
     TUNE_COUNT
 };
 int tune(int id);

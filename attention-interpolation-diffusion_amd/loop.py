@@ -176,7 +176,12 @@ class AidDenoiseLoop:
             def uncond_pass():
                 set_aid_active(self.unet, False)
                 return self.unet(self.sample, self.uncond)
-            return fork_join(cond_pass, uncond_pass, self._side)
+            from . import ops
+            ops.set_tuning("CU_SHARE", 2)               # two launch streams share the device: the GEMM engine choice plans with half the CUs
+            try:
+                return fork_join(cond_pass, uncond_pass, self._side)
+            finally:
+                ops.set_tuning("CU_SHARE", -1)
         if which == "cond_aid":
             set_aid_active(self.unet, True, plain_tail=0)
             return self.unet(self.sample, self.cond)

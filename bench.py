@@ -70,11 +70,12 @@ def parse():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K steps until the timed region is this long")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--passes", default="auto", choices=["auto", "batched", "streams", "serial"],
-                    help="the cond and the uncond pass of a step: ONE UNet call over [cond ; uncond] (batched; same work, same results "
-                         "as the reference's two calls) | two UNet calls on two streams, forked and joined inside one graph (streams) | "
-                         "two UNet calls back to back like the reference loop (serial).  auto: batched for the SDXL text workloads, "
-                         "streams for sd15 (its small launches do not fill the device: 5.66 -> 5.39 ms/step) and for ip (two different "
-                         "image embeddings cannot share a call)")
+                    help="the cond and the uncond pass of a step: ONE UNet call over [cond ; uncond] (batched; how stock diffusers "
+                         "pipelines batch CFG) | two UNet calls on two streams, forked and joined inside one graph (streams; the library "
+                         "is told that two launch streams share the device: CU_SHARE = 2) | two UNet calls back to back like the reference "
+                         "loop (serial).  All three give the same results.  auto: batched for the SDXL text workloads (streams is faster "
+                         "there too, `also.sdxl_two_streams`, but halves every launch), streams for sd15 (5.71 -> 5.37 ms/step) and ip "
+                         "(cannot batch: its passes carry different image embeddings)")
     ap.add_argument("--separate-passes", action="store_true", help="alias of --passes serial")
     ap.add_argument("--guide-prompt", default="auto", choices=["auto", "on", "off"],
                     help="PAID: interior frames share the guide prompt's text context (3 distinct contexts)")
@@ -150,7 +151,9 @@ def roofline_pass(loop, aid_amd, torch):
     lib = aid_amd._lib.load()
     was, was_conc = loop.use_graphs, getattr(loop, "concurrent_cfg", False)
     loop.use_graphs = False
-    loop.concurrent_cfg = False                                  # every kernel alone on the device: the two passes back to back
+    loop.concurrent_cfg = False                                  # every kernel alone on the device: the two passes back to back ...
+    if was_conc:
+        aid_amd.ops.set_tuning("CU_SHARE", 2)                    # ... launched as in the two-stream run (engine choice for half the CUs)
     loop.step(0); loop.step(loop.num_inference_steps - 1)        # eager warm-up
     torch.cuda.synchronize()
     lib.aid_profile_begin()
@@ -159,6 +162,8 @@ def roofline_pass(loop, aid_amd, torch):
     buf = (aid_amd._lib.AidProfileEntry * 8192)()
     n = lib.aid_profile_end(buf, 8192)
     loop.use_graphs, loop.concurrent_cfg = was, was_conc
+    if was_conc:
+        aid_amd.ops.set_tuning("CU_SHARE", -1)
     if n < 0:
         raise RuntimeError(lib.aid_strerror(n).decode())
     agg = {}
@@ -332,7 +337,10 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
     local_coef = coef[list(shard.index)]
     passes = "serial" if args.separate_passes else args.passes
     if passes == "auto":
-        passes = "streams" if (name in ("sd15", "ip") and not exch) else "batched"    # (exchange layout: collectives per layer, one stream)
+        # sd15: small launches, two streams fill the device better; ip: cannot batch.  The SDXL text workloads are faster on two
+        # streams as well (36.8 -> 35.7 ms/step, `also.sdxl_two_streams`) but stay batched by default: every launch then owns the
+        # device, which keeps the per-kernel roofline of the top-level line unambiguous and comparable across rounds
+        passes = "streams" if (name in ("sd15", "ip") and not exch) else "batched"
     if name == "ip" and passes == "batched":
         raise SystemExit("--workload ip: the two passes carry different image embeddings (--passes streams | serial)")
     batched = passes == "batched"
@@ -529,8 +537,19 @@ def main():
                                        "ms_per_step": t3["ms_per_step"], "repeats": t3["repeats"], "dtype": "f16"}
         del w3
         torch.cuda.empty_cache()
-        # ... and with the text keys / values projected in every call, like the reference
+        # ... on two streams (the reference's two UNet calls, concurrently) instead of one batched call
         args.dtype = None
+        if args.passes == "auto" and not args.separate_passes:
+            args.passes = "streams"
+            w5 = build_workload("sdxl", args, world, rank, device, torch, aid_amd)
+            t5 = time_workload(w5, args, world, device, torch, dist)
+            result["also"]["sdxl_two_streams"] = {"value": t5["value"], "unit": "frames/s", "ms_per_step": t5["ms_per_step"],
+                                                  "repeats": t5["repeats"], "dtype": w5["dtype"],
+                                                  "passes_per_step": "two UNet calls on two streams inside one graph, CU_SHARE = 2"}
+            args.passes = "auto"
+            del w5
+            torch.cuda.empty_cache()
+        # ... and with the text keys / values projected in every call, like the reference
         if not args.no_text_kv_cache:
             aproc.TEXT_KV_CACHE = False
             w4 = build_workload("sdxl", args, world, rank, device, torch, aid_amd)

@@ -308,7 +308,10 @@ const char* aid_last_gemm_variant(void);
  * loaded, from environment variables AID_<NAME>; this call changes an entry at run time (value < 0 = back to the
  * heuristic).  Nothing on the launch path reads the environment.  Every value a knob accepts selects among kernels that compute the
  * same result; a value outside a knob's range is refused (AID_ERR_ARG) here and ignored in the environment — no setting can make the
- * library skip work.  Returns AID_ERR_ARG for an unknown name. */
+ * library skip work.  Returns AID_ERR_ARG for an unknown name.
+ * One knob is a HINT about the caller rather than a development switch: "CU_SHARE" = n (1 .. 8) says that n independent launch
+ * streams run side by side (e.g. the conditional and the unconditional UNet call of a step on two streams); the GEMM engine choice then
+ * plans with 1 / n of the CUs.  Results do not depend on it. */
 int aid_set_tuning(const char* name, int value);
 /* current value of a knob (-1 = the launch heuristics decide) */
 int aid_get_tuning(const char* name, int* value);
