@@ -56,3 +56,27 @@ def test_two_stream_passes_equal_serial_passes(ip, graphs):
         for k in a:
             assert torch.isfinite(a[k].float()).all() and torch.equal(a[k], b[k]), k
     assert not torch.equal(outs[0][0][unet.level_shapes()[0]], outs[0][2][unet.level_shapes()[0]])   # AID and plain steps differ
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_cu_share_hint_changes_the_engine_not_the_result(dtype, tuning):
+    """CU_SHARE = n (n launch streams share the device) only moves the GEMM engine choice: the same bits come out of the projection
+    shapes of a two-stream SDXL / SD1.5 step under every value, through whichever engine the hint selects."""
+    from aid_amd import ops
+    g = torch.Generator().manual_seed(17)
+    picked = set()
+    for m, n, k in ((7168, 1280, 1280), (28672, 640, 640), (28672, 320, 320), (3584, 1280, 1280), (8192, 1280, 2048)):
+        x = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(DEV)
+        w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dtype).to(DEV)
+        b = torch.randn(n, generator=g).to(dtype).to(DEV)
+        outs = []
+        for share in (-1, 2, 4, 8):
+            tuning("CU_SHARE", share)
+            outs.append(ops.linear(x, w, b))
+            picked.add((m, share, ops.last_gemm_variant()))
+        torch.cuda.synchronize()
+        ref = (x.float() @ w.float().T + b.float())
+        assert float((outs[0].float() - ref).norm() / ref.norm()) < (1e-3 if dtype == torch.float16 else 8e-3)
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), (m, n, k)
+    assert len({v for (m, s, v) in picked if m == 7168}) > 1, picked          # the hint did move the choice for the half-round launch
