@@ -15,8 +15,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AID_LIB_PATH") or os.path.join(PKG_DIR, "libaid_hip.so")   # override: development A/B builds
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
-AID_ABI_VERSION = 6
-DTYPE_F16, DTYPE_BF16 = 0, 1
+AID_ABI_VERSION = 7
+DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
 MODE_PLAIN, MODE_INNER, MODE_OUTER = 0, 1, 2
 GEMM_MAX_PROBLEMS = 6
 IP_NONE, IP_SAME, IP_PLAIN = 0, 1, 2
@@ -25,7 +25,7 @@ IP_NONE, IP_SAME, IP_PLAIN = 0, 1, 2
 ABI_SYMBOLS = (
     "aid_gemm_nt", "aid_layernorm", "aid_ln_stats", "aid_ln_fold", "aid_attn_fwd", "aid_lerp_kv", "aid_processor_workspace_bytes", "aid_processor_fwd",
     "aid_abi_version", "aid_strerror", "aid_last_attn_variant", "aid_last_gemm_variant", "aid_device_info",
-    "aid_profile_begin", "aid_profile_end", "aid_set_tuning", "aid_get_tuning",
+    "aid_profile_begin", "aid_profile_end", "aid_set_tuning", "aid_get_tuning", "aid_stream_capture_id",
 )
 
 
@@ -39,6 +39,7 @@ class AidGemmProblem(C.Structure):
         ("residual", C.c_void_p),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_shift", C.c_void_p),
         ("ln_side", C.c_int32), ("trans_rows", C.c_int32), ("stride_stats", C.c_int64),
+        ("cu_share", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -76,6 +77,7 @@ class AidProcessorArgs(C.Structure):
         ("ip_begin", C.c_int32), ("ip_end", C.c_int32), ("seg_executed", C.c_int32), ("kv_cached_lt", C.c_int32),
         ("ln_wq", C.c_void_p), ("ln_wk", C.c_void_p), ("ln_wv", C.c_void_p), ("ln_const", C.c_void_p),
         ("k_cached", C.c_void_p), ("vt_cached", C.c_void_p),
+        ("cu_share", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -149,6 +151,8 @@ def bind(path: str) -> C.CDLL:
     lib.aid_profile_begin.restype = C.c_int
     lib.aid_profile_end.restype = C.c_int
     lib.aid_profile_end.argtypes = [C.POINTER(AidProfileEntry), C.c_int]
+    lib.aid_stream_capture_id.restype = C.c_int
+    lib.aid_stream_capture_id.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     if lib.aid_abi_version() != AID_ABI_VERSION:
         raise RuntimeError(f"libaid_hip.so ABI version {lib.aid_abi_version()} != expected {AID_ABI_VERSION}; rebuild")
     return lib

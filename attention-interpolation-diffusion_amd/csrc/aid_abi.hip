@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "aid_kernels.hpp"
@@ -27,14 +29,16 @@ struct ProfRec {
     char name[64];
     double flops, bytes, flops_exec;
 };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;                      // guards g_prof: launches of several host threads may be profiled at once
 std::vector<ProfRec> g_prof;
 
 struct ProfScope {          // records an event pair around one launch when profiling is on
     hipStream_t stream;
     bool on;
+    size_t idx = 0;         // this launch's record (other threads may append while the launch is being issued)
     ProfScope(hipStream_t s, const char* name, double flops, double bytes, double flops_exec = -1.0)
-        : stream(s), on(g_prof_on) {
+        : stream(s), on(g_prof_on.load(std::memory_order_relaxed)) {
         if (!on) return;
         ProfRec r;
         (void)hipEventCreate(&r.t0);
@@ -44,37 +48,47 @@ struct ProfScope {          // records an event pair around one launch when prof
         r.bytes = bytes;
         r.flops_exec = flops_exec < 0.0 ? flops : flops_exec;
         (void)hipEventRecord(r.t0, stream);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        idx = g_prof.size();
         g_prof.push_back(r);
     }
     void rename(const char* name) {      // the kernel symbol is known only after the launcher picked an engine
-        if (on) snprintf(g_prof.back().name, sizeof(g_prof.back().name), "%s", name);
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (idx < g_prof.size()) snprintf(g_prof[idx].name, sizeof(g_prof[idx].name), "%s", name);
     }
     ~ProfScope() {
-        if (on) (void)hipEventRecord(g_prof.back().t1, stream);
+        if (!on) return;
+        hipEvent_t t1 = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            if (idx < g_prof.size()) t1 = g_prof[idx].t1;
+        }
+        if (t1) (void)hipEventRecord(t1, stream);
     }
 };
 
 // ---- tuning knobs (aid_kernels.hpp: enum Tune) -----------------------------------------------------
 const char* const g_tune_names[aid::TUNE_COUNT] = {"GEMM_VARIANT", "GEMM_PP", "GEMM_TRI", "ATTN_NW", "ATTN_QB", "ATTN_PIPE",
-                                                   "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2", "CU_SHARE"};
+                                                   "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2", "CU_SHARE", "GEMM_RS"};
 // Largest value a knob accepts.  Every accepted value selects between kernels / launch shapes that compute THE SAME RESULT (the parity
 // suite runs under each of them); values beyond the range are refused by aid_set_tuning and ignored in the environment.  The timing
 // ablations (kernels that skip work, "results are garbage") exist only in development builds (-DAID_ABLATIONS, tools/dev/Makefile ->
 // tools/dev/libaid_abl.so) and are addressed through the same table there.
 #ifdef AID_ABLATIONS
-const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1, 8};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1, 8, 1};
 #else
-const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1, 8};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1};
 #endif
 struct TuneTable {
-    int v[aid::TUNE_COUNT];
+    std::atomic<int> v[aid::TUNE_COUNT];        // independent integers: a knob flipped by one thread is seen by the launches of all
     TuneTable() {                               // runs once, when the library is loaded
         for (int i = 0; i < aid::TUNE_COUNT; ++i) {
             char name[64];
             snprintf(name, sizeof(name), "AID_%s", g_tune_names[i]);
             const char* e = getenv(name);
             const int x = (e && *e) ? atoi(e) : -1;
-            v[i] = (x < 0 || x > g_tune_max[i]) ? -1 : x;
+            v[i].store((x < 0 || x > g_tune_max[i]) ? -1 : x, std::memory_order_relaxed);
         }
     }
 };
@@ -83,6 +97,9 @@ TuneTable g_tune;
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+inline bool dtype16(int d) { return d == AID_DTYPE_F16 || d == AID_DTYPE_BF16; }
+inline bool dtype_ok(int d) { return dtype16(d) || d == AID_DTYPE_F32; }
+inline const char* dtype_name(int d) { return d == AID_DTYPE_F16 ? "f16" : d == AID_DTYPE_BF16 ? "bf16" : "f32"; }
 
 int check_problem(const AidGemmProblem& q) {
     if (!q.a || !q.b || !q.c) return AID_ERR_ARG;
@@ -106,7 +123,7 @@ struct Carve {
 
 Carve carve(const AidProcessorArgs& a) {
     Carve c;
-    const size_t es = 2;
+    const size_t es = a.dtype == AID_DTYPE_F32 ? 4 : 2;
     const int nctx = a.ctx ? a.n_ctx : a.n_frames;
     const int l = a.ctx ? a.l : a.s;
     c.lp = round_up(l, 8);
@@ -135,7 +152,8 @@ Carve carve(const AidProcessorArgs& a) {
 
 int check_processor(const AidProcessorArgs& a) {
     if (!a.x || !a.wq || !a.wk || !a.wv || !a.wo || !a.y) return AID_ERR_ARG;
-    if (a.dtype != AID_DTYPE_F16 && a.dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (!dtype_ok(a.dtype)) return AID_ERR_DTYPE;
+    if (a.dtype == AID_DTYPE_F32 && a.ln_eps > 0.f) return AID_ERR_DTYPE;      // the LayerNorm fusion is 16-bit only
     if (a.n_frames < 1 || a.s < 1 || a.c < 1 || a.heads < 1 || a.c % a.heads) return AID_ERR_ARG;
     if (a.mode < AID_MODE_PLAIN || a.mode > AID_MODE_OUTER) return AID_ERR_ARG;
     if (a.mode != AID_MODE_PLAIN && !a.coef) return AID_ERR_ARG;
@@ -163,7 +181,7 @@ int check_processor(const AidProcessorArgs& a) {
     if ((a.k_cached != nullptr) != (a.vt_cached != nullptr)) return AID_ERR_ARG;
     if (a.k_cached && (!a.ctx || !aligned16(a.k_cached) || !aligned16(a.vt_cached))) return AID_ERR_ARG;
     if (a.kv_cached_lt != 0 && (!a.k_cached || a.mode == AID_MODE_INNER || a.kv_cached_lt % 64 || a.kv_cached_lt < a.l)) return AID_ERR_ARG;
-    if (!(a.ln_eps >= 0.f)) return AID_ERR_ARG;
+    if (!(a.ln_eps >= 0.f) || a.cu_share < 0 || a.cu_share > 8) return AID_ERR_ARG;
     if (a.ln_eps > 0.f) {
         if (!aid::layernorm_width_supported(a.c)) return AID_ERR_SHAPE;
         if ((a.ln_gamma && !aligned16(a.ln_gamma)) || (a.ln_beta && !aligned16(a.ln_beta))) return AID_ERR_SHAPE;
@@ -178,7 +196,7 @@ int check_processor(const AidProcessorArgs& a) {
 }  // namespace
 
 namespace aid {
-int tune(int id) { return (id >= 0 && id < TUNE_COUNT) ? g_tune.v[id] : -1; }
+int tune(int id) { return (id >= 0 && id < TUNE_COUNT) ? g_tune.v[id].load(std::memory_order_relaxed) : -1; }
 }  // namespace aid
 
 extern "C" {
@@ -191,7 +209,7 @@ int aid_set_tuning(const char* name, int value) {
     for (int i = 0; i < aid::TUNE_COUNT; ++i)
         if (!strcmp(name, g_tune_names[i])) {
             if (value > g_tune_max[i]) return AID_ERR_ARG;      // no value may change results (see g_tune_max)
-            g_tune.v[i] = value < 0 ? -1 : value;
+            g_tune.v[i].store(value < 0 ? -1 : value, std::memory_order_relaxed);
             return AID_OK;
         }
     return AID_ERR_ARG;
@@ -202,7 +220,7 @@ int aid_get_tuning(const char* name, int* value) {
     if (!strncmp(name, "AID_", 4)) name += 4;
     for (int i = 0; i < aid::TUNE_COUNT; ++i)
         if (!strcmp(name, g_tune_names[i])) {
-            *value = g_tune.v[i];
+            *value = g_tune.v[i].load(std::memory_order_relaxed);
             return AID_OK;
         }
     return AID_ERR_ARG;
@@ -212,7 +230,7 @@ const char* aid_strerror(int code) {
     switch (code) {
         case AID_OK: return "ok";
         case AID_ERR_ARG: return "invalid argument (NULL pointer, negative size or inconsistent field)";
-        case AID_ERR_DTYPE: return "unsupported dtype (AID_DTYPE_F16 / AID_DTYPE_BF16 only)";
+        case AID_ERR_DTYPE: return "unsupported dtype (AID_DTYPE_F16 / _BF16 / _F32; the LayerNorm entry points and fusion options are 16-bit only)";
         case AID_ERR_SHAPE: return "unsupported shape or alignment (head dim must be 40/64/80/160; see aid_hip.h)";
         case AID_ERR_WORKSPACE: return "workspace too small or misaligned";
         case AID_ERR_LAUNCH: return g_err[0] ? g_err : "kernel launch failed";
@@ -235,15 +253,27 @@ int aid_device_info(int* n_cu, int* clock_khz, char* arch) {
     return AID_OK;
 }
 
+int aid_stream_capture_id(void* stream, unsigned long long* id) {
+    if (!id) return AID_ERR_ARG;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    const hipError_t e = hipStreamGetCaptureInfo(static_cast<hipStream_t>(stream), &st, &cid);
+    if (e != hipSuccess) return fail_hip(e, "aid_stream_capture_id");
+    *id = st == hipStreamCaptureStatusActive ? cid : 0ull;
+    return AID_OK;
+}
+
 int aid_profile_begin(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
     g_prof.clear();
-    g_prof_on = true;
+    g_prof_on.store(true);
     return AID_OK;
 }
 
 int aid_profile_end(AidProfileEntry* entries, int max_entries) {
-    g_prof_on = false;
+    g_prof_on.store(false);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     int n = 0;
     int rc = AID_OK;
     for (auto& r : g_prof) {
@@ -268,7 +298,8 @@ int aid_profile_end(AidProfileEntry* entries, int max_entries) {
 
 int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void* stream) {
     if (!problems || n_problems < 1 || n_problems > AID_GEMM_MAX_PROBLEMS) return AID_ERR_ARG;
-    if (dtype != AID_DTYPE_F16 && dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (!dtype_ok(dtype)) return AID_ERR_DTYPE;
+    if (problems[0].cu_share < 0 || problems[0].cu_share > 8) return AID_ERR_ARG;
     aid::GemmGroup g;
     memset(&g, 0, sizeof(g));
     g.n_problems = n_problems;
@@ -291,7 +322,7 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
         }
     }
     double flops = 0, bytes = 0;
-    if (g_prof_on) {
+    if (g_prof_on.load(std::memory_order_relaxed)) {
         for (int i = 0; i < n_problems; ++i) {
             const AidGemmProblem& q = problems[i];
             flops += 2.0 * q.m * q.n * q.k * q.batch;
@@ -302,16 +333,23 @@ int aid_gemm_nt(const AidGemmProblem* problems, int n_problems, int dtype, void*
     }
     hipError_t e;
     {
-        ProfScope ps(static_cast<hipStream_t>(stream), "aid_gemm_nt", flops, bytes);
-        e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream), &g_gemm_variant);
-        // profile entries carry the kernel SYMBOL that ran, so they line up with rocprofv3's per-kernel rows
-        char nm[64];
-        const char* sym = !strncmp(g_gemm_variant, "pingpong288", 11) ? "aid_gemm_nt_ppx_kernel"
-                          : !strncmp(g_gemm_variant, "pingpong", 8)   ? "aid_gemm_nt_pp_kernel"
-                          : !strcmp(g_gemm_variant, "edge")           ? "aid_gemm_nt_kernel"
-                                                                      : "aid_gemm_nt_pipe_kernel";
-        snprintf(nm, sizeof(nm), "%s<%s>", sym, dtype == AID_DTYPE_F16 ? "f16" : "bf16");
-        ps.rename(nm);
+        ProfScope ps(static_cast<hipStream_t>(stream), "aid_gemm_nt", flops, dtype == AID_DTYPE_F32 ? 2.0 * bytes : bytes);
+        if (dtype == AID_DTYPE_F32) {
+            e = aid::gemm_f32_launch(g, static_cast<hipStream_t>(stream));
+            g_gemm_variant = "f32";
+            ps.rename("aid_gemm_f32_kernel");
+        } else {
+            e = aid::gemm_group_launch(g, dtype, static_cast<hipStream_t>(stream), &g_gemm_variant, problems[0].cu_share);
+            // profile entries carry the kernel SYMBOL that ran, so they line up with rocprofv3's per-kernel rows
+            char nm[64];
+            const char* sym = !strncmp(g_gemm_variant, "rowstat", 7)      ? "aid_gemm_rs_kernel"
+                              : !strncmp(g_gemm_variant, "pingpong288", 11) ? "aid_gemm_nt_ppx_kernel"
+                              : !strncmp(g_gemm_variant, "pingpong", 8)   ? "aid_gemm_nt_pp_kernel"
+                              : !strcmp(g_gemm_variant, "edge")           ? "aid_gemm_nt_kernel"
+                                                                          : "aid_gemm_nt_pipe_kernel";
+            snprintf(nm, sizeof(nm), "%s<%s>", sym, dtype_name(dtype));
+            ps.rename(nm);
+        }
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_gemm_nt");
 }
@@ -359,7 +397,7 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     if (!args) return AID_ERR_ARG;
     const AidAttnArgs& a = *args;
     if (!a.q || !a.k || !a.vt || !a.out) return AID_ERR_ARG;
-    if (a.dtype != AID_DTYPE_F16 && a.dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (!dtype_ok(a.dtype)) return AID_ERR_DTYPE;
     if (a.mode < AID_MODE_PLAIN || a.mode > AID_MODE_OUTER) return AID_ERR_ARG;
     if (a.n_frames < 1 || a.n_kv < 1 || a.s < 1 || a.l < 1 || a.heads < 1) return AID_ERR_ARG;
     if (a.mode != AID_MODE_PLAIN && (!a.coef || a.begin < 0 || a.begin >= a.n_kv || a.end < 0 || a.end >= a.n_kv))
@@ -379,6 +417,16 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     const double flops_exec = a.seg_executed > 0 ? per_seg * a.seg_executed : flops;
     const double bytes = 2.0 * (2.0 * a.n_frames * a.s * c + 2.0 * a.n_kv * a.l * c);
     hipError_t e = hipSuccess;
+    if (a.dtype == AID_DTYPE_F32) {             // float32 storage: one correctness-first kernel for every mode (aid_f32.hip)
+        char nm[64];
+        snprintf(nm, sizeof(nm), "aid_attn_f32<d%d,%s>", a.d, a.mode == AID_MODE_PLAIN ? "plain" : a.mode == AID_MODE_INNER ? "inner" : "outer");
+        {
+            ProfScope ps(static_cast<hipStream_t>(stream), nm, flops, 2.0 * bytes, flops_exec);
+            e = aid::attn_f32_launch(a, static_cast<hipStream_t>(stream));
+        }
+        g_variant = "aid_attn_f32";
+        return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
+    }
     // d = 64, whole key tiles: the ping-pong kernel (aid_attn_pp.hip).  It runs every kind of frame — one key segment (PLAIN, riders,
     // fused end points), two (fused INNER, one-sided OUTER), three (fused OUTER) — deciding per frame ON THE DEVICE from the
     // coefficients like aid_attn_kernel; the host-side counts below only attribute the work.
@@ -432,16 +480,19 @@ static int lerp_kv_impl(const void* k, const void* vt, void* k2, void* vt2, cons
                         int32_t begin, int32_t end, int64_t k_fs, int64_t vt_fs, int32_t dtype, void* stream,
                         int n_interior) {
     if (!k || !vt || !k2 || !vt2 || !coef || n_frames < 1 || begin < 0 || end < 0) return AID_ERR_ARG;
-    if (dtype != AID_DTYPE_F16 && dtype != AID_DTYPE_BF16) return AID_ERR_DTYPE;
+    if (!dtype_ok(dtype)) return AID_ERR_DTYPE;
     if (k_fs % 8 || vt_fs % 8 || !aligned16(k) || !aligned16(vt) || !aligned16(k2) || !aligned16(vt2)) return AID_ERR_SHAPE;
     hipError_t e;
     {
         // algorithmic traffic: the two end-point frames read once, one interpolated row written per interior frame
         const double elems = (double)(k_fs + vt_fs);
-        ProfScope ps(static_cast<hipStream_t>(stream), dtype == AID_DTYPE_F16 ? "aid_lerp_kv<f16>" : "aid_lerp_kv<bf16>",
-                     3.0 * n_interior * elems, 2.0 * (2.0 + n_interior) * elems);
-        e = aid::lerp_kv_launch(k, vt, k2, vt2, coef, n_frames, begin, end, k_fs, vt_fs, dtype,
-                                static_cast<hipStream_t>(stream));
+        ProfScope ps(static_cast<hipStream_t>(stream), dtype == AID_DTYPE_F16 ? "aid_lerp_kv<f16>" : dtype == AID_DTYPE_BF16 ? "aid_lerp_kv<bf16>" : "aid_lerp_kv<f32>",
+                     3.0 * n_interior * elems, (dtype == AID_DTYPE_F32 ? 4.0 : 2.0) * (2.0 + n_interior) * elems);
+        if (dtype == AID_DTYPE_F32)
+            e = aid::lerp_kv_f32_launch(k, vt, k2, vt2, coef, n_frames, begin, end, k_fs, vt_fs, static_cast<hipStream_t>(stream));
+        else
+            e = aid::lerp_kv_launch(k, vt, k2, vt2, coef, n_frames, begin, end, k_fs, vt_fs, dtype,
+                                    static_cast<hipStream_t>(stream));
     }
     return e == hipSuccess ? AID_OK : fail_hip(e, "aid_lerp_kv");
 }
@@ -496,6 +547,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     pr[0].m = a.n_frames * a.s; pr[0].n = a.c; pr[0].k = a.c;
     pr[0].lda = a.c; pr[0].ldb = a.c; pr[0].ldc = a.c; pr[0].batch = 1;
     pr[0].scale = 1.4426950408889634f / sqrtf((float)d);      // softmax_scale * log2(e) folded into q before its rounding
+    pr[0].cu_share = a.cu_share;
     pr[1].a = e;    pr[1].b = a.wk; pr[1].c = ws + cv.k;
     pr[1].m = nctx * l; pr[1].n = a.c; pr[1].k = cc;
     pr[1].lda = cc; pr[1].ldb = cc; pr[1].ldc = a.c; pr[1].batch = 1;
@@ -541,6 +593,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     if (cached) {                                             // the query projection (and the image keys / values) only
         for (int i = 3; i < npr; ++i) pr[i - 2] = pr[i];
         npr -= 2;
+        pr[0].cu_share = a.cu_share;
     }
     rc = aid_gemm_nt(pr, npr, a.dtype, stream);
     if (rc != AID_OK) return rc;
@@ -582,6 +635,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
         AidAttnArgs ai = at;
         ai.k = kip; ai.vt = vtip; ai.k2 = nullptr; ai.vt2 = nullptr;
         ai.kv_map = a.ip_map; ai.n_kv = a.n_ip; ai.l = a.t_ip;
+        ai.kv_padded = 0;                                 // the image keys / values are laid out compactly, whatever the text keys are
         ai.ldk = a.c; ai.ldvt = cv.tp;
         ai.k_fs = (int64_t)a.t_ip * a.c; ai.vt_fs = (int64_t)a.c * cv.tp;
         ai.accumulate = 1; ai.out_scale = a.ip_scale; ai.frame_scale = a.ip_frame_scale;
@@ -601,6 +655,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     po.a = o; po.b = a.wo; po.c = a.y; po.bias = a.bo; po.residual = a.residual;
     po.m = a.n_frames * a.s; po.n = a.c; po.k = a.c;
     po.lda = a.c; po.ldb = a.c; po.ldc = a.c; po.batch = 1;
+    po.cu_share = a.cu_share;
     return aid_gemm_nt(&po, 1, a.dtype, stream);
 }
 

@@ -1020,7 +1020,9 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     // barrier) as 16-byte stores covering whole rows of the head — 8-byte stores per lane at a row stride are store-ISSUE bound (the
     // guide's T21; profiles/r04_attn_notes.txt): the 77-key launches, little more than a store tail, -9 ... -18 %.
     constexpr bool STAGED = !RES && QB == 1 && D % 8 == 0 && (size_t)NBUF * (KT * KLD + DV * VLD) * sizeof(T) >= (size_t)NW * 32 * D * sizeof(T);
-    const bool staged = STAGED && a.ldo % 8 == 0 && a.o_fs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+    // (an accumulating launch — the IP-Adapter image branch — takes the direct path: there the old output is added in fp32 and the sum
+    // rounded ONCE, whatever the alignment; the staged path would round the new term first: one numeric behaviour)
+    const bool staged = STAGED && !a.accumulate && a.ldo % 8 == 0 && a.o_fs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
                         (int64_t)a.n_frames * a.o_fs * 2 < (1ll << 31);
     if (STAGED && staged) {
         __syncthreads();                                        // every wave is done with the K / V^T tiles
@@ -1054,7 +1056,6 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     T8 v = *reinterpret_cast<const T8*>(stg + row * RBY + ((SWZ ? cc ^ ((row >> 1) & 7) : cc) << 4));
                     const int q = q0 + row;
                     const int vo = (min(q, a.s - 1) * a.ldo + cc * 8) * 2;
-                    if (a.accumulate) v = cvt8<T>(up8<T>(v) + up8<T>(__builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(ro, vo, so, 0))));
                     if (q < a.s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, so, 0);
                 }
             }

@@ -1655,23 +1655,23 @@ static void untranspose(GemmGroup& g) {
 }
 
 template <typename T>
-static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char** variant, bool dry, bool* is_ppx);
+static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char** variant, bool dry, bool* is_ppx, int cu_share);
 
 template <typename T>
-static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** variant) {
+static hipError_t launch_gemm(GemmGroup& g, hipStream_t stream, const char** variant, int cu_share) {
     if (has_trans(g)) {
         GemmGroup probe = g;
         bool ppx = false;
-        const hipError_t e = launch_gemm_sel<T>(probe, stream, nullptr, true, &ppx);
+        const hipError_t e = launch_gemm_sel<T>(probe, stream, nullptr, true, &ppx, cu_share);
         if (e != hipSuccess) return e;
         if (!ppx) untranspose(g);
     }
-    return launch_gemm_sel<T>(g, stream, variant, false, nullptr);
+    return launch_gemm_sel<T>(g, stream, variant, false, nullptr, cu_share);
 }
 
 // dry: pick the engine only (*is_ppx = the 288-row engine would run the main problems), launch nothing
 template <typename T>
-static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char** variant, bool dry, bool* is_ppx) {
+static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char** variant, bool dry, bool* is_ppx, int cu_share) {
     bool k64 = true;
     for (int i = 0; i < g.n_problems; ++i) k64 = k64 && (g.p[i].k % 64 == 0);
     if (!k64) {
@@ -1687,8 +1687,19 @@ static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char**
     if (ncu <= 0) return hipErrorInvalidDevice;
     // CU_SHARE = n: n launch streams share the device (the two passes of a step on two streams): a launch can count on 1 / n of the
     // CUs, so e.g. 125 tiles of 288 rows are a full round, not half of one (SDXL, two streams: 39.0 -> 37.3 ms/step)
-    const int share = tune(TUNE_CU_SHARE);
+    // (the per-call value — AidGemmProblem.cu_share — wins over the process-wide knob)
+    const int share = cu_share > 1 ? cu_share : tune(TUNE_CU_SHARE);
     if (share > 1) ncu = (ncu / share + 7) / 8 * 8;
+    // short K, tall shared activation (C = 320 / 640 levels): the row-stationary engine (aid_gemm_rs.hip) — the activation rows stay in
+    // registers, the weights stream through LDS; it writes transposed problems itself.  GEMM_RS: 0 never, 1 wherever the shape allows.
+    {
+        const int rs = tune(TUNE_GEMM_RS);
+        if (rs != 0 && force < 0 && gemm_rs_supported(g, ncu, rs == 1)) {
+            if (dry) { *is_ppx = true; return hipSuccess; }           // (a transposed problem stays as it is)
+            if (variant) *variant = g.p[0].k == 640 ? "rowstat640" : "rowstat320";
+            return gemm_rs_launch(g, std::is_same<T, f16>::value ? AID_DTYPE_F16 : AID_DTYPE_BF16, ncu, stream);
+        }
+    }
     bool pp = false;
     PpPlan pl = {};
     GemmSide sd;
@@ -1771,7 +1782,7 @@ static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char**
     return launch_pipe<T, 128, 128, 64, 2, 2, 4>(g, stream);       // 8 waves, 64 x 32 wave tiles, 2 workgroups / CU
 }
 
-hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const char** variant) {
+hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const char** variant, int cu_share) {
     // Longest K loop first: blocks are dispatched in grid order, so the tiles that take longest (the K = 2048
     // text-context projections of a cross-attention layer next to its K = 1280 query projection) start first
     // and finish under the rest instead of forming the tail of the launch (measured: 107 -> 7x us).
@@ -1784,7 +1795,7 @@ hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const 
             g.p[j] = g.p[j - 1];
             g.p[j - 1] = t;
         }
-    return dtype == AID_DTYPE_F16 ? launch_gemm<f16>(g, stream, variant) : launch_gemm<bf16>(g, stream, variant);
+    return dtype == AID_DTYPE_F16 ? launch_gemm<f16>(g, stream, variant, cu_share) : launch_gemm<bf16>(g, stream, variant, cu_share);
 }
 
 }  // namespace aid

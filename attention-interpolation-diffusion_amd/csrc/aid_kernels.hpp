@@ -61,12 +61,25 @@ enum Tune {
     TUNE_ATTN_V2,               // ping-pong d = 64 kernel: 0 never / 1 wherever supported; default: fused OUTER l >= 1024, everything else l >= 2048
     TUNE_CU_SHARE,              // n > 1: the caller runs n independent launch streams side by side (two passes on two streams): the GEMM
                                 // engine choice plans with 1 / n of the CUs; a hint, results never depend on it
+    TUNE_GEMM_RS,               // row-stationary engine for the short-K levels (aid_gemm_rs.hip): 0 = never, 1 = wherever the shape allows;
+                                // default: wherever the shape allows AND the activation has enough row tiles to fill the device
     TUNE_COUNT
 };
 int tune(int id);
 
 // picks the tile shape, fills g.tile_start and launches
-hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const char** variant = nullptr);
+// cu_share > 1: the caller runs that many launch streams side by side (AidGemmProblem.cu_share); 0 / 1: the process-wide CU_SHARE knob decides
+hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const char** variant = nullptr, int cu_share = 0);
+
+// row-stationary engine (aid_gemm_rs.hip): K = 320 / 640, one shared tall activation; `ncu` = CUs the launch may count on
+bool       gemm_rs_supported(const GemmGroup& g, int ncu, bool ignore_size);
+hipError_t gemm_rs_launch(const GemmGroup& g, int dtype, int ncu, hipStream_t stream);
+
+// float32 storage path (aid_f32.hip)
+hipError_t gemm_f32_launch(GemmGroup& g, hipStream_t stream);
+hipError_t attn_f32_launch(const AidAttnArgs& a, hipStream_t stream);
+hipError_t lerp_kv_f32_launch(const void* k, const void* vt, void* k2, void* vt2, const float* coef, int n_frames, int begin,
+                              int end, int64_t k_fs, int64_t vt_fs, hipStream_t stream);
 
 // attention core; returns hipSuccess / error, writes the variant name for profiling
 // skip_single: the frames with ONE key segment are left to the ping-pong kernel (attn_pp_launch on the same stream)

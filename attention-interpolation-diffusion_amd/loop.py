@@ -149,6 +149,8 @@ class AidDenoiseLoop:
         self.use_graphs = use_graphs
         self.combine = combine or self._cfg
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self._warmed: set = set()
+        self._cap = None
         self._outs: Dict[str, object] = {}
 
     def _cfg(self, text, uncond):
@@ -177,16 +179,27 @@ class AidDenoiseLoop:
                 set_aid_active(self.unet, False)
                 return self.unet(self.sample, self.uncond)
             from . import ops
-            ops.set_tuning("CU_SHARE", 2)               # two launch streams share the device: the GEMM engine choice plans with half the CUs
-            try:
+            self._warm_pair(which, cond_pass, uncond_pass)
+            with ops.cu_share(2):                       # two launch streams share the device: every call of both passes plans with half the CUs
                 return fork_join(cond_pass, uncond_pass, self._side)
-            finally:
-                ops.set_tuning("CU_SHARE", -1)
         if which == "cond_aid":
             set_aid_active(self.unet, True, plain_tail=0)
             return self.unet(self.sample, self.cond)
         set_aid_active(self.unet, False)
         return self.unet(self.sample, self.cond if which == "cond_plain" else self.uncond)
+
+    def _warm_pair(self, which: str, cond_pass: Callable, uncond_pass: Callable) -> None:
+        """The first forked step of a kind on cold caches: ``cond_pass`` fills lazily built shared state on the current
+        stream — the folded LayerNorm weights, the text K / V cache — that ``uncond_pass`` reads on the side stream, and ``fork_join``
+        orders the side stream behind the fork point only.  So the pair runs ONCE back to back on the current stream first (outputs
+        dropped); every forked step after that finds the caches filled.  (Graph mode warms up the same way before its capture.)"""
+        if which in self._warmed:
+            return
+        self._warmed.add(which)
+        if torch.cuda.is_current_stream_capturing():
+            return                                      # the eager warm-up of _run() has been here already
+        cond_pass()
+        uncond_pass()
 
     def _run(self, which: str):
         if not self.use_graphs:
@@ -194,14 +207,16 @@ class AidDenoiseLoop:
         g = self._graphs.get(which)
         if g is None:
             cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):              # warm-up: lazy kernel attributes, coef caches, workspaces
+            if self._cap is None:
+                self._cap = torch.cuda.Stream()         # warm-up AND capture stream of this loop: the capture adopts the warm-up's workspace
+            cap = self._cap
+            cap.wait_stream(cur)
+            with torch.cuda.stream(cap):                # warm-up: lazy kernel attributes, coef caches, workspaces (ops.workspace)
                 self._pass(which)
-            cur.wait_stream(side)
+            cur.wait_stream(cap)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=cap):
                 self._outs[which] = self._pass(which)
             self._graphs[which] = g
         g.replay()

@@ -33,6 +33,8 @@ a guide-prompt run share one projected text context (``ctx_index``).
 """
 from __future__ import annotations
 
+import warnings
+
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -176,18 +178,21 @@ class _PassGraphs:
         self.enabled = bool(enabled)
         self.fallback_reason: Optional[str] = None
         self._ent: Dict[Any, Tuple] = {}
+        self._cap = None
 
     def _capture(self, fn: Callable, inputs: Dict[str, torch.Tensor]):
         static = {k: v.clone() for k, v in inputs.items()}
         cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
+        if self._cap is None:
+            self._cap = torch.cuda.Stream()         # warm-up AND capture stream: the capture adopts the warm-up's workspace (ops.workspace)
+        cap = self._cap
+        cap.wait_stream(cur)
+        with torch.cuda.stream(cap):
             fn(**static)
-        cur.wait_stream(side)
+        cur.wait_stream(cap)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=cap):
             out = fn(**static)
         return graph, static, out
 
@@ -198,11 +203,18 @@ class _PassGraphs:
         if ent is None:
             try:
                 ent = self._capture(fn, inputs)
-            except Exception as e:              # noqa: BLE001 — anything a foreign UNet does that a stream capture forbids
+            except RuntimeError as e:           # what a foreign UNet does that a stream capture forbids surfaces as RuntimeError
+                # (hipErrorStreamCaptureUnsupported & co. through torch); anything else is a bug and propagates.  The fallback is
+                # loud: a run that silently lost its graphs is a large performance regression
                 self.enabled = False
                 self.fallback_reason = f"{type(e).__name__}: {e}"
                 self._ent.clear()
-                torch.cuda.synchronize()
+                warnings.warn("hipGraph capture of a UNet pass failed, the run continues eagerly: " + self.fallback_reason,
+                              RuntimeWarning, stacklevel=3)
+                try:
+                    torch.cuda.synchronize()    # an invalidated capture may leave a sticky error behind: report it, do not hide it
+                except RuntimeError as e2:
+                    raise RuntimeError(f"device unusable after a failed stream capture ({self.fallback_reason})") from e2
                 return fn(**inputs)
             self._ent[key] = ent
         graph, static, out = ent

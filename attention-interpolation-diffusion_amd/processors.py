@@ -8,8 +8,8 @@ methods (``activate(t)``, ``deactivate()``, ``load_end_point``) as the reference
 
 The arithmetic of every call — q/k/v projection, end-point K/V interpolation, the fused
 softmax(QK^T/sqrt(d))V with own-key fusion, the outer/inner lerp and the output projection —
-runs in ``libaid_hip.so`` (hand-written gfx950 kernels).  There is no eager / CPU fallback:
-CPU tensors, fp32 tensors or a missing library raise.
+runs in ``libaid_hip.so`` (hand-written gfx950 kernels; fp16 / bf16 storage on the fast kernels, fp32 storage — the reference's
+SD1.x default — on correctness-first fp32 kernels).  There is no eager / CPU fallback: CPU tensors or a missing library raise.
 
 Differences from the reference that are deliberate and documented:
   * de-activated processors with ``original_attn=None`` run plain attention on the same HIP
@@ -360,7 +360,8 @@ def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tens
 def _plain_sublayer_ok(attn, hidden_states) -> bool:
     """The one-call form  h + attn(norm(h))  covers the transformer-block attention of SD / SDXL: 3-D input and none of
     the Attention extras (spatial / group norm, own residual connection, output rescale, cross-attention norm)."""
-    return (hidden_states.ndim == 3 and getattr(attn, "spatial_norm", None) is None
+    return (hidden_states.ndim == 3 and hidden_states.dtype != torch.float32       # (fp32 storage: norm, call, add as three steps)
+            and getattr(attn, "spatial_norm", None) is None
             and getattr(attn, "group_norm", None) is None and not getattr(attn, "residual_connection", False)
             and getattr(attn, "rescale_output_factor", 1.0) == 1.0 and not getattr(attn, "norm_cross", None))
 
@@ -402,9 +403,16 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
         # the concatenated tensor [distinct local contexts ; two end-point contexts] is loop-invariant: built ONCE per
         # (caller's context tensor, map) — no per-call host -> device copy in front of the side-stream exchange —
         # and it is the tensor the text K / V cache keys on
-        ck = ("exchange", tuple(base), ctx.data_ptr(), _version_of(ctx), tuple(ctx.shape), proc.endpoint_ctx.data_ptr(),
-              _version_of(proc.endpoint_ctx))
+        ectx = proc.endpoint_ctx
+        ck = ("exchange", tuple(base), ctx.data_ptr(), _version_of(ctx), tuple(ctx.shape), ctx.dtype, ctx.device,
+              ectx.data_ptr(), _version_of(ectx), tuple(ectx.shape), ectx.dtype, ectx.device)
         hit = proc._ctx_cache.get(ck)
+        # an entry is only as good as the two tensors it was built from: a fresh prompt-embedding tensor at a recycled address
+        # (same shape, version 0) must not find the previous prompt's contexts — the weak references say whether the
+        # objects are still THE objects, and their callbacks drop the entry when either tensor dies
+        if hit is not None and (hit[1]() is not ctx or hit[2]() is not ectx):
+            proc._ctx_cache.pop(ck, None)
+            hit = None
         if hit is None:
             own = ctx
             if own.shape[0] == n and nctx != n:
@@ -413,7 +421,9 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
                 raise RuntimeError(f"encoder_hidden_states has {ctx.shape[0]} rows; the frame -> context map needs {nctx}")
             for old_key in [k_ for k_ in proc._ctx_cache if k_ and k_[0] == "exchange"]:
                 proc._ctx_cache.pop(old_key, None)                # one live entry per processor (per run)
-            hit = (torch.cat([own, proc.endpoint_ctx.to(ctx.dtype)], dim=0).contiguous(), weakref.ref(ctx))
+            def _drop(_ref, cache=proc._ctx_cache, key=ck):
+                cache.pop(key, None)
+            hit = (torch.cat([own, ectx.to(ctx.dtype)], dim=0).contiguous(), weakref.ref(ctx, _drop), weakref.ref(ectx, _drop))
             proc._ctx_cache[ck] = hit
         full = hit[0]
         full_map = base + [nctx, nctx + 1]

@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--passes", default="auto", choices=["auto", "batched", "streams", "serial"],
                     help="the cond and the uncond pass of a step: ONE UNet call over [cond ; uncond] (batched; how stock diffusers "
                          "pipelines batch CFG) | two UNet calls on two streams, forked and joined inside one graph (streams; the library "
-                         "is told that two launch streams share the device: CU_SHARE = 2) | two UNet calls back to back like the reference "
+                         "is told per call that two launch streams share the device: cu_share = 2) | two UNet calls back to back like the reference "
                          "loop (serial).  All three give the same results.  auto: batched for the SDXL text workloads (streams is faster "
                          "there too, `also.sdxl_two_streams`, but halves every launch), streams for sd15 (5.71 -> 5.37 ms/step) and ip "
                          "(cannot batch: its passes carry different image embeddings)")
@@ -152,18 +152,17 @@ def roofline_pass(loop, aid_amd, torch):
     was, was_conc = loop.use_graphs, getattr(loop, "concurrent_cfg", False)
     loop.use_graphs = False
     loop.concurrent_cfg = False                                  # every kernel alone on the device: the two passes back to back ...
-    if was_conc:
-        aid_amd.ops.set_tuning("CU_SHARE", 2)                    # ... launched as in the two-stream run (engine choice for half the CUs)
-    loop.step(0); loop.step(loop.num_inference_steps - 1)        # eager warm-up
-    torch.cuda.synchronize()
-    lib.aid_profile_begin()
-    loop.step(0)                                                 # AID step
-    loop.step(loop.num_inference_steps - 1)                      # plain step
-    buf = (aid_amd._lib.AidProfileEntry * 8192)()
-    n = lib.aid_profile_end(buf, 8192)
+    import contextlib
+    # ... launched as in the two-stream run (per-call hint cu_share = 2: engine choice for half the CUs)
+    with (aid_amd.ops.cu_share(2) if was_conc else contextlib.nullcontext()):
+        loop.step(0); loop.step(loop.num_inference_steps - 1)    # eager warm-up
+        torch.cuda.synchronize()
+        lib.aid_profile_begin()
+        loop.step(0)                                             # AID step
+        loop.step(loop.num_inference_steps - 1)                  # plain step
+        buf = (aid_amd._lib.AidProfileEntry * 8192)()
+        n = lib.aid_profile_end(buf, 8192)
     loop.use_graphs, loop.concurrent_cfg = was, was_conc
-    if was_conc:
-        aid_amd.ops.set_tuning("CU_SHARE", -1)
     if n < 0:
         raise RuntimeError(lib.aid_strerror(n).decode())
     agg = {}
@@ -545,7 +544,7 @@ def main():
             t5 = time_workload(w5, args, world, device, torch, dist)
             result["also"]["sdxl_two_streams"] = {"value": t5["value"], "unit": "frames/s", "ms_per_step": t5["ms_per_step"],
                                                   "repeats": t5["repeats"], "dtype": w5["dtype"],
-                                                  "passes_per_step": "two UNet calls on two streams inside one graph, CU_SHARE = 2"}
+                                                  "passes_per_step": "two UNet calls on two streams inside one graph, cu_share = 2 per call"}
             args.passes = "auto"
             del w5
             torch.cuda.empty_cache()

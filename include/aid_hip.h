@@ -36,11 +36,16 @@
 extern "C" {
 #endif
 
-#define AID_ABI_VERSION 6
+#define AID_ABI_VERSION 7
 
 /* element types of activations / weights (accumulation is always fp32) */
 #define AID_DTYPE_F16  0
 #define AID_DTYPE_BF16 1
+/* ABI v7: float32 tensors in and out, float32 arithmetic (v_mfma_f32_32x32x2_f32, the f32 vector rate) — the reference's own default
+ * for SD1.x (gradio_src/app.py:62, 414) and its CPU path.  aid_gemm_nt, aid_attn_fwd, aid_lerp_kv and aid_processor_fwd take it
+ * (probabilities are then not rounded before the PV product, like the reference's float32 get_attention_scores); the LayerNorm
+ * entry points and the ln_* / residual-fusion options of aid_processor_fwd are 16-bit only (AID_ERR_DTYPE). */
+#define AID_DTYPE_F32  2
 
 /* image branch of the IP-Adapter processors (AidProcessorArgs.ip_mode) */
 #define AID_IP_NONE       0
@@ -104,6 +109,11 @@ typedef struct AidGemmProblem {
     /* (Same numbers as the batched form  V^T[f] = Wv E_f^T; the library picks whichever its tile engines run faster.)    */
     int32_t      trans_rows;
     int64_t      stride_stats;
+    /* ABI v7.  cu_share (read from problems[0]): n > 1 says that n independent launch streams of the CALLER run side by side (the   */
+    /* conditional and the unconditional UNet call of a step on two streams), so this launch should plan with 1 / n of the CUs —    */
+    /* a per-call hint (two host threads may pass different values); results never depend on it.  0 / 1: the whole device.          */
+    int32_t      cu_share;
+    int32_t      reserved0;
 } AidGemmProblem;
 
 int aid_gemm_nt(const AidGemmProblem* problems /* host */, int n_problems, int dtype, void* stream);
@@ -269,6 +279,8 @@ typedef struct AidProcessorArgs {
     /* the query projection alone.  Only valid with ctx != NULL; the caller owns the buffers and their validity.             */
     const void*  k_cached;
     const void*  vt_cached;
+    int32_t      cu_share;       /* ABI v7: see AidGemmProblem.cu_share — handed to every GEMM launch of the call            */
+    int32_t      reserved1;
 } AidProcessorArgs;
 
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args /* host */);
@@ -303,20 +315,27 @@ const char* aid_strerror(int code);
 const char* aid_last_attn_variant(void);
 /* same for the last aid_gemm_nt launch: "lockstep128", "pingpong256" (+ "+tail128") or "edge" */
 const char* aid_last_gemm_variant(void);
+/* Thread safety (ABI v7): every entry point may be called from several host threads at once, each on its own stream with its own
+ * workspace.  The tuning table is a set of independent atomic integers (a knob flipped by one thread is seen by the launches of all),
+ * the profiling list is guarded by a mutex and collects the launches of every thread between begin and end, the error / variant
+ * strings are thread-local. */
 /* Development / tuning knobs (kernel-variant choices the launch heuristics normally make: "GEMM_VARIANT", "GEMM_PP",
  * "ATTN_NW", "ATTN_RES", ... — the list is in csrc/aid_kernels.hpp).  The table is filled ONCE when the library is
  * loaded, from environment variables AID_<NAME>; this call changes an entry at run time (value < 0 = back to the
  * heuristic).  Nothing on the launch path reads the environment.  Every value a knob accepts selects among kernels that compute the
  * same result; a value outside a knob's range is refused (AID_ERR_ARG) here and ignored in the environment — no setting can make the
  * library skip work.  Returns AID_ERR_ARG for an unknown name.
- * One knob is a HINT about the caller rather than a development switch: "CU_SHARE" = n (1 .. 8) says that n independent launch
- * streams run side by side (e.g. the conditional and the unconditional UNet call of a step on two streams); the GEMM engine choice then
- * plans with 1 / n of the CUs.  Results do not depend on it. */
+ * "CU_SHARE" = n (1 .. 8) is the process-wide default of the per-call hint AidGemmProblem.cu_share / AidProcessorArgs.cu_share (n
+ * independent launch streams run side by side; the GEMM engine choice plans with 1 / n of the CUs) for callers that cannot pass it per
+ * call; a per-call value > 0 wins.  Results do not depend on it. */
 int aid_set_tuning(const char* name, int value);
 /* current value of a knob (-1 = the launch heuristics decide) */
 int aid_get_tuning(const char* name, int* value);
 /* device properties of the current device: returns AID_OK and fills what is non-NULL */
 int aid_device_info(int* n_cu, int* clock_khz, char* arch /* >= 32 bytes */);
+/* ABI v7.  *id = the id of the stream capture `stream` is part of (hipStreamGetCaptureInfo), 0 when it is not capturing.  Callers that
+ * own scratch memory use it to give every capture its own (the Python layer never allocates a workspace inside a capture). */
+int aid_stream_capture_id(void* stream, unsigned long long* id);
 
 #ifdef __cplusplus
 }

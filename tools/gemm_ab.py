@@ -29,6 +29,11 @@ SHAPES = [("sdxl L2 qkv 3x(14336,1280,1280)", [(14336, 1280, 1280)] * 3),
           ("square 8192^3", [(8192, 8192, 8192)])]
 if "--ksweep" in sys.argv:
     SHAPES = [(f"4096x4096x{k}", [(4096, 4096, k)]) for k in (128, 640, 1280, 2560, 5120)]
+if "--short" in sys.argv:        # the short-K levels (row-stationary engine, GEMM_RS): batched-CFG call and one pass of a two-stream step
+    SHAPES = [("sdxl L1 qkv 3x(57344,640,640)", [(57344, 640, 640)] * 3), ("sdxl L1 out (57344,640,640)", [(57344, 640, 640)]),
+              ("sdxl L1 qkv 3x(28672,640,640)", [(28672, 640, 640)] * 3), ("sdxl L1 out (28672,640,640)", [(28672, 640, 640)]),
+              ("sd15 L0 qkv 3x(57344,320,320)", [(57344, 320, 320)] * 3), ("sd15 L0 out (57344,320,320)", [(57344, 320, 320)]),
+              ("sd15 L0 qkv 3x(28672,320,320)", [(28672, 320, 320)] * 3), ("sd15 L0 out (28672,320,320)", [(28672, 320, 320)])]
 if "--sd15" in sys.argv:
     SHAPES = [("sd15 L0 qkv 3x(57344,320,320)", [(57344, 320, 320)] * 3), ("sd15 L0 out", [(57344, 320, 320)]),
               ("sd15 L1 qkv 3x(14336,640,640)", [(14336, 640, 640)] * 3), ("sd15 L1 out", [(14336, 640, 640)]),
@@ -45,7 +50,7 @@ def timed(fn):
 
 
 def apply(v):
-    for name in ("GEMM_VARIANT", "GEMM_PP", "GEMM_TRI"):
+    for name in ("GEMM_VARIANT", "GEMM_PP", "GEMM_TRI", "GEMM_RS", "CU_SHARE"):
         ops.set_tuning(name, v.get(name, -1))
 
 
