@@ -90,7 +90,10 @@ __global__ __launch_bounds__(256) void aid_gemm_f32_kernel(const GemmGroup g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int n = n0 + wn + 8 * gq + 4 * hi + e;
-            if (n >= P.n) continue;
+            if (n >= P.n) {                                        // columns [n, round_up(n, 4)) are written with zeros (aid_hip.h)
+                if (!P.trans_rows && n < (P.n + 3) / 4 * 4) C[(int64_t)m * P.ldc + n] = 0.f;
+                continue;
+            }
             float v = acc[4 * gq + e];
             if (stats) {                                           // folded LayerNorm: rstd (x W'^T - mean colsum) + shift
                 if (P.ln_side == 1) v = fmaf(stats[2 * m + 1], fmaf(-stats[2 * m], P.ln_colsum[n], v), P.ln_shift[n]);

@@ -1694,7 +1694,9 @@ static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char**
     // registers, the weights stream through LDS; it writes transposed problems itself.  GEMM_RS: 0 never, 1 wherever the shape allows.
     {
         const int rs = tune(TUNE_GEMM_RS);
-        if (rs != 0 && force < 0 && gemm_rs_supported(g, ncu, rs == 1)) {
+        // (the size rule looks at the DEVICE's CU count, not at the share the caller's hint leaves: the engine choice between this engine
+        //  and the tile engines — whose summation orders differ — must not depend on cu_share; only the split of the slice range does)
+        if (rs != 0 && force < 0 && gemm_rs_supported(g, num_cu(), rs == 1)) {
             if (dry) { *is_ppx = true; return hipSuccess; }           // (a transposed problem stays as it is)
             if (variant) *variant = g.p[0].k == 640 ? "rowstat640" : "rowstat320";
             return gemm_rs_launch(g, std::is_same<T, f16>::value ? AID_DTYPE_F16 : AID_DTYPE_BF16, ncu, stream);

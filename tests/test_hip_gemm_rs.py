@@ -1,6 +1,7 @@
 """GPU parity of the row-stationary projection engine (csrc/aid_gemm_rs.hip): the short-K levels of the UNets — attn.to_q / to_k /
 to_v / to_out[0] at C = 320 (SD1.5, S = 4096) and C = 640 (SDXL, S = 4096), reference interpolation.py:613, 623-624, 666 — against
-fp64 and, bit for bit, against the tile engines of aid_gemm.hip on the same operands."""
+fp64 and against the tile engines of aid_gemm.hip on the same operands (same products, another fp32 summation grouping: equal up to
+the storage type's last place on the rare sum that sits on a rounding boundary)."""
 import numpy as np
 import pytest
 import torch
@@ -17,6 +18,15 @@ DTYPES = [torch.float16, torch.bfloat16]
 ids_dt = lambda d: str(d).split(".")[-1]  # noqa: E731
 
 
+def _same(a, b, dtype):
+    """Two engines, one product: identical storage values except for isolated last-place differences."""
+    a, b = a.float(), b.float()
+    diff = (a - b).abs()
+    ulp = (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7) * torch.maximum(a.abs(), b.abs()).clamp_min(1e-3)
+    assert bool((diff <= 1.01 * ulp).all()), float((diff / ulp).max())
+    assert float((diff > 0).float().mean()) < 0.02, float((diff > 0).float().mean())
+
+
 def _operands(m, n, k, dtype, seed, n_w=1):
     g = torch.Generator().manual_seed(seed)
     a = (torch.randn(m, k, generator=g) + 0.3).to(dtype).to(DEV)
@@ -28,12 +38,12 @@ def _operands(m, n, k, dtype, seed, n_w=1):
 @pytest.mark.parametrize("m,n,k", [(2048, 640, 640),        # 8 row tiles: the slice range of a tile is split over workgroups
                                    (1024, 320, 320),        # K = 320: two weight rows per 1280-B virtual row
                                    (512, 1280, 640),        # more columns than K
-                                   (256, 64, 320),          # one slice pair
+                                   (256, 96, 320),          # three slices
                                    (57344, 640, 640),       # SDXL level 1 out projection at full size (the default rule takes it)
                                    (28672, 320, 320)])      # SD1.5 level 0, one pass of a two-stream step
 def test_single_projection_bias_scale_residual(dtype, m, n, k, tuning):
-    """One projection with scale, bias and the residual added after the rounding: fp64 within the GEMM tolerance and bit-identical
-    to the tile engines (same k order, one fp32 accumulator)."""
+    """One projection with scale, bias and the residual added after the rounding: fp64 within the GEMM tolerance, and the tile
+    engines' values."""
     g, a, (w,) = _operands(m, n, k, dtype, m + n + k)
     bias = torch.randn(n, generator=g).to(dtype).to(DEV)
     res = torch.randn(m, n, generator=g).to(dtype).to(DEV)
@@ -51,12 +61,12 @@ def test_single_projection_bias_scale_residual(dtype, m, n, k, tuning):
     got = to_np64(outs[1][rows])
     assert torch.isfinite(outs[1]).all()
     assert rel_l2(got, ref) < TOL_GEMM[dtype] and worst(got, ref) < WORST[dtype]
-    assert torch.equal(outs[1], outs[0])
+    _same(outs[1], outs[0], dtype)
     # the default rule: tall activations only
     tuning("GEMM_RS", -1)
     y = torch.empty(m, n, dtype=dtype, device=DEV)
     ops.gemm_nt([dict(a=a, b=w, c=y, m=m, n=n, k=k, lda=k, ldb=k, ldc=n)])
-    assert ops.last_gemm_variant().startswith("rowstat") == (m >= 16384), ops.last_gemm_variant()
+    assert ops.last_gemm_variant().startswith("rowstat") == (m >= (49152 if k == 320 else 16384)), ops.last_gemm_variant()
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
@@ -90,7 +100,7 @@ def test_grouped_qkv_with_transposed_values(dtype, frames, keys, c, tuning):
     ref_v = to_np64(wv) @ to_np64(x[f * keys:(f + 1) * keys]).T                     # V^T of the last frame, every key
     assert rel_l2(to_np64(vt[f]), ref_v) < TOL_GEMM[dtype] and worst(to_np64(vt[f]), ref_v) < WORST[dtype]
     for a_, b_ in zip(outs[1], outs[0]):
-        assert torch.equal(a_, b_)
+        _same(a_, b_, dtype)
 
 
 def test_unsupported_groups_fall_back_to_the_tile_engines(tuning):
