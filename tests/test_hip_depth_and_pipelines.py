@@ -73,10 +73,11 @@ def _oracle_layer(stack, i, h64, ctx64, mode, fused, coef):
 # BOUNDS: rel-L2 of the residual stream after the LAST layer of each resolution level (HIP storage dtype vs fp64).
 # One sublayer measures ~3e-4 (fp16) / ~2.5e-3 (bf16) on the attention term; the stream itself is re-rounded to the
 # storage dtype after every layer (eps/2 = 2.4e-4 fp16, 2e-3 bf16 relative per rounding), errors add in quadrature over
-# the L layers of a level.  Bounds = ~2x the measured values (gpurun_out/depth_parity.json, profiles/r02_depth_parity.json).
+# the L layers of a level.  Bounds = 1.3 x the measured values (profiles/r05_depth_parity.json: 8.0e-4 / 1.46e-2 / 1.78e-3; the runs are
+# deterministic, the margin is for other boxes' clocks changing nothing and for future kernel changes to have to argue).
 # SDXL in fp16 storage (the kernels serve d = 64 in both dtypes): the 140-layer stream stays at the fp16 level — this is the
 # configuration that meets north_star's 1e-3 per layer; bf16 pays 8x the rounding step.
-DEPTH_BOUND = {("sd15", torch.float16): 2e-3, ("sdxl", torch.bfloat16): 3e-2, ("sdxl", torch.float16): 4e-3}
+DEPTH_BOUND = {("sd15", torch.float16): 1.05e-3, ("sdxl", torch.bfloat16): 1.9e-2, ("sdxl", torch.float16): 2.35e-3}
 
 
 @pytest.mark.parametrize("model,dtype,early", [("sd15", torch.float16, "fused_inner"), ("sdxl", torch.bfloat16, "fused_outer"),
@@ -115,11 +116,26 @@ class OracleDenoiser(torch.nn.Module):
     """StackDenoiser.forward in fp64 with every attention layer evaluated by the oracle; reads the activation state /
     coefficients / riders of the processors installed on the HIP denoiser it mirrors."""
 
-    def __init__(self, hip: StackDenoiser):
+    def __init__(self, hip: StackDenoiser, storage: "torch.dtype | None" = None):
+        """``storage``: round to that dtype at every point where ANY implementation that keeps its tensors in that dtype must round —
+        the projected q / k / v, the attention output, the layer output and the residual stream — and nowhere else (fp64 arithmetic,
+        un-rounded probabilities, exact LayerNorm): the FLOOR of the storage type for this loop, independent of any kernel."""
         super().__init__()
         self.hip = hip
+        self.storage = storage
         self.latent_hw, self.in_channels = hip.latent_hw, 4
         self.dummy = torch.nn.Parameter(torch.zeros(1, dtype=torch.float64), requires_grad=False)
+
+    def _layer(self, st, i, h, ctx, mode, fused, coef):
+        if self.storage is None:
+            return _oracle_layer(st, i, h, ctx, mode, fused, coef)
+        rd = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.storage).double().numpy()      # noqa: E731
+        m, nrm, (s, c, heads, is_cross) = st.layers[i], st.norms[i], st.shapes[i]
+        hn = O.layer_norm(h, to_np64(nrm.weight), to_np64(nrm.bias), nrm.eps)
+        w = _w(m, heads)
+        q, k, v = O._project(hn, ctx if is_cross else None, w)
+        o = O.attn_core(rd(q), rd(k), rd(v), heads, w.scale, mode, fused and mode != "plain", coef)
+        return rd(h + rd(O._out(rd(o), w)))
 
     attn_processors = property(lambda self: self.hip.attn_processors)
 
@@ -129,13 +145,17 @@ class OracleDenoiser(torch.nn.Module):
     def forward(self, sample, timestep=None, encoder_hidden_states=None, added_cond_kwargs=None, return_dict=False, **kw):
         st = self.hip.stack
         n = sample.shape[0]
-        flat = sample.reshape(n, -1).double().numpy()
+        # (storage mode also rounds where the scaffolding around the layers stores: the latents and embeddings handed in, the lifted
+        # tokens, the stream the first layer reads, the predicted noise)
+        rd = (lambda a: a) if self.storage is None else \
+            (lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.storage).double().numpy())
+        flat = rd(sample.reshape(n, -1).double().numpy())
         tshift = 0.0 if timestep is None else float(timestep) * self.hip.time_scale
         hs = {}
         for (s, c) in st.level_shapes():
-            tok = (flat @ to_np64(self.hip.lift[f"{s}_{c}"])).reshape(n, s, 8)
-            hs[(s, c)] = np.tile(tok, (1, 1, c // 8)) + tshift
-        ctx_all = encoder_hidden_states.double().numpy()
+            tok = rd(flat @ to_np64(self.hip.lift[f"{s}_{c}"])).reshape(n, s, 8)
+            hs[(s, c)] = rd(np.tile(tok, (1, 1, c // 8)) + tshift)
+        ctx_all = rd(encoder_hidden_states.double().numpy())
         for i, (m, (s, c, h, is_cross)) in enumerate(zip(st.layers, st.shapes)):
             proc = m.processor
             n_aid = n - proc.plain_tail if proc.activated else 0
@@ -150,24 +170,37 @@ class OracleDenoiser(torch.nn.Module):
             coef = proc.coef.to(self.hip.dtype).float().numpy()
             hcur = hs[(s, c)]
             if mode == "plain":
-                hs[(s, c)] = _oracle_layer(st, i, hcur, ctx, "plain", False, None)
+                hs[(s, c)] = self._layer(st, i, hcur, ctx, "plain", False, None)
             else:
-                a = _oracle_layer(st, i, hcur[:n_aid], ctx[:n_aid], mode, proc.is_fused, coef)
+                a = self._layer(st, i, hcur[:n_aid], ctx[:n_aid], mode, proc.is_fused, coef)
                 if n_aid < n:
-                    a = np.concatenate([a, _oracle_layer(st, i, hcur[n_aid:], ctx[n_aid:], "plain", False, None)])
+                    a = np.concatenate([a, self._layer(st, i, hcur[n_aid:], ctx[n_aid:], "plain", False, None)])
                 hs[(s, c)] = a
         out = np.zeros_like(flat)
         for (s, c) in st.level_shapes():
             hm = hs[(s, c)].reshape(n, s, c // 8, 8).mean(axis=2)
             out = out + hm.reshape(n, s * 8) @ to_np64(self.hip.drop[f"{s}_{c}"])
-        out = out / len(st.level_shapes())
+        out = rd(out / len(st.level_shapes()))
         return (torch.from_numpy(out).view_as(sample),)
 
     def parameters(self, recurse=True):
         return iter([self.dummy])
 
 
-PIPE_BOUND = {torch.float16: 5e-3, torch.bfloat16: 4e-2}     # rel-L2 of the final latents, ~2x measured
+class StorageScheduler(DDIMSchedulerLite):
+    """DDIM with the guided noise and the latents rounded to a storage dtype where a loop that keeps them in that dtype rounds them
+    (the arithmetic of the step itself stays un-rounded) — the scheduler side of OracleDenoiser(storage=...)."""
+
+    def __init__(self, storage, **kw):
+        super().__init__(**kw)
+        self.storage = storage
+
+    def step(self, model_output, timestep, sample, **kw):
+        rd = lambda a: a.to(self.storage).to(a.dtype)          # noqa: E731
+        return (rd(super().step(rd(model_output), timestep, rd(sample), **kw)[0]),)
+
+
+PIPE_BOUND = {torch.float16: 2.5e-3, torch.bfloat16: 2.1e-2}     # rel-L2 of the final latents, 1.3 x measured (1.92e-3 / 1.60e-2)
 
 
 def _embs(g, cc, xl=False):
@@ -289,9 +322,11 @@ def test_n_frame_interpolate_end_to_end_vs_oracle_loop(guided):
 # layer evaluated by the fp64 oracle.  All 32 / 140 layers at reduced S; the default also divides heads and widths together (head_div:
 # head dims 40 / 80 / 160 / 64 kept, so the shipped kernels run) because the fp64 loop is bound by the weight bytes (SDXL: 8.4 GB of
 # fp64 weights per pass at full width); AID_E2E_FULL_WIDTH=1 runs the full widths (tools/refresh_profiles.sh does, once per round).
-# STATED TOLERANCE of the final latents after 50 steps (rel-L2 vs fp64; ~2x the measured values of profiles/r04_depth_parity.json):
-# measured (round 4): SD1.5 fp16 1.3e-3 / 1.4e-3 (single / 7 frames), SDXL fp16 1.8e-3, SDXL bf16 1.5e-2 / 1.7e-2
-E2E50_BOUND = {("sd15", torch.float16): 4e-3, ("sdxl", torch.float16): 4e-3, ("sdxl", torch.bfloat16): 4e-2}
+# STATED TOLERANCE of the final latents after 50 steps (rel-L2 vs fp64) = 1.3 x the largest value measured for the configuration
+# (profiles/r05_depth_parity.json; VERDICT r4 next #5b: a 2x bound lets a doubling of the accumulated error pass):
+# measured (round 5): SD1.5 fp16 1.32e-3 / 1.36e-3 (single / 7 frames; 1.41e-3 at full width), SDXL fp16 1.80e-3 (1.54e-3 at full width),
+# SDXL bf16 1.52e-2 / 1.67e-2
+E2E50_BOUND = {("sd15", torch.float16): 1.85e-3, ("sdxl", torch.float16): 2.35e-3, ("sdxl", torch.bfloat16): 2.2e-2}
 E2E50 = [("sd15", torch.float16, "fused_inner"), ("sdxl", torch.bfloat16, "fused_outer"), ("sdxl", torch.float16, "fused_outer")]
 E2E50_N7 = E2E50 if os.environ.get("AID_E2E_ALL") == "1" else E2E50[:2]      # (the fp64 loop of a 14-frame SDXL run takes a minute)
 
@@ -342,3 +377,57 @@ def test_seven_frame_interpolate_50_steps_vs_oracle_loop(model, dtype, atype):
     _record(f"e2e50_n7_{model}_{str(dtype).split('.')[-1]}" + ("_fullwidth" if full else ""),
             dict(steps=50, rel_l2=err, per_frame=per_frame))
     assert out.shape == (7, 4, 8, 8) and torch.isfinite(out).all() and err < E2E50_BOUND[(model, dtype)], (err, per_frame)
+
+
+def test_interpolate_single_50_steps_sdxl_fp16_at_full_width():
+    """One FULL-WIDTH 50-step case in the suite the driver runs (VERDICT r4 next #5a; the cases above divide heads and widths together
+    unless AID_E2E_FULL_WIDTH=1): SDXL, fp16 storage, all 140 attention layers at their real widths (C = 640 / 1280, 10 / 20 heads),
+    interpolate_single, HIP against the fp64 oracle loop."""
+    dtype, model = torch.float16, "sdxl"
+    hip = StackDenoiser(model, dtype=dtype, device=DEV, scale_down=64, latent_hw=(8, 8), head_div=1)
+    g = torch.Generator().manual_seed(50)
+    l0, l1 = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    rd = lambda t: tuple(e.to(dtype).float() for e in t)     # noqa: E731
+    es, ee = rd(_embs(g, hip.stack.cross_dim, True)), rd(_embs(g, hip.stack.cross_dim, True))
+    kw = dict(num_inference_steps=50, warmup_ratio=0.5, guidance_scale=5.0, output_type="latent")
+    pipe = InterpolationStableDiffusionXLPipeline(hip, DDIMSchedulerLite())
+    pipe.load_aid(t=0.5, is_fused=True, atype="fused_outer")
+    out = pipe.interpolate_single(0.35, latent_start=l0, latent_end=l1, embeds_start=es, embeds_end=ee, **kw)["images"]
+    ora = InterpolationStableDiffusionXLPipeline(OracleDenoiser(hip), DDIMSchedulerLite())
+    ref = ora.interpolate_single(0.35, latent_start=l0.to(dtype).double(), latent_end=l1.to(dtype).double(),
+                                 embeds_start=tuple(e.double() for e in es), embeds_end=tuple(e.double() for e in ee), **kw)["images"]
+    err = rel_l2(to_np64(out), ref.numpy())
+    _record("e2e50_single_sdxl_float16_fullwidth_suite", dict(steps=50, rel_l2=err))
+    assert out.shape == (3, 4, 8, 8) and torch.isfinite(out).all() and err < E2E50_BOUND[(model, dtype)], err
+
+
+@pytest.mark.parametrize("model,dtype,atype", [("sd15", torch.float16, "fused_inner"), ("sdxl", torch.float16, "fused_outer")],
+                         ids=lambda v: str(v).split(".")[-1])
+def test_fp16_storage_floor_of_the_50_step_loop(model, dtype, atype):
+    """north_star's "latents within 1e-3 rel-L2" against what fp16 STORAGE alone costs (VERDICT r4 next #5d).  The same 50-step loop
+    in fp64 ARITHMETIC, rounded to fp16 only where a loop that keeps its tensors in fp16 stores them — q / k / v, the attention
+    output, the layer output and the residual stream; the latents and embeddings handed to the denoiser, the predicted noise, the
+    guided noise and the latents the scheduler returns (StorageScheduler) — with un-rounded probabilities and exact LayerNorm, i.e.
+    better than any kernel can be, against the un-rounded fp64 loop.  That is the floor of the storage type: measured 1.25e-3 (SD1.5,
+    32 layers) and 1.73e-3 (SDXL, 140 layers), ABOVE 1e-3 — which is why the fp16 rows of E2E50_BOUND are not 1e-3.  (Rounding only
+    inside the attention layers gives 2.3e-4 / 1.06e-3: for SD1.5 most of the floor is the fp16 latents / noise of the loop around the
+    layers, which the reference's fp16 pipeline stores the same way.)  The HIP path measures 1.32e-3 / 1.80e-3: within 6 % of the floor,
+    asserted at 1.15x — the kernels' own roundings (fp16 probabilities, the pre-scaled q, folded LayerNorm weights) add almost nothing,
+    so the lever VERDICT r4 names (row sums from the un-rounded probabilities) has nothing left to recover."""
+    hip, full = _e2e50_denoiser(model, dtype)
+    cls = InterpolationStableDiffusionXLPipeline if model == "sdxl" else InterpolationStableDiffusionPipeline
+    g = torch.Generator().manual_seed(50)
+    l0, l1 = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    rd = lambda t: tuple(e.to(dtype).float() for e in t)     # noqa: E731
+    es, ee = rd(_embs(g, hip.stack.cross_dim, model == "sdxl")), rd(_embs(g, hip.stack.cross_dim, model == "sdxl"))
+    kw = dict(num_inference_steps=50, warmup_ratio=0.5, guidance_scale=5.0, output_type="latent")
+    pipe = cls(hip, DDIMSchedulerLite())
+    pipe.load_aid(t=0.5, is_fused=True, atype=atype)
+    out = pipe.interpolate_single(0.35, latent_start=l0, latent_end=l1, embeds_start=es, embeds_end=ee, **kw)["images"]
+    args = dict(latent_start=l0.to(dtype).double(), latent_end=l1.to(dtype).double(), embeds_start=tuple(e.double() for e in es),
+                embeds_end=tuple(e.double() for e in ee), **kw)
+    ref = cls(OracleDenoiser(hip), DDIMSchedulerLite()).interpolate_single(0.35, **args)["images"].numpy()
+    floor = cls(OracleDenoiser(hip, storage=dtype), StorageScheduler(dtype)).interpolate_single(0.35, **args)["images"].numpy()
+    e_hip, e_floor = rel_l2(to_np64(out), ref), rel_l2(floor, ref)
+    _record(f"storage_floor_{model}_float16", dict(steps=50, hip_rel_l2=e_hip, storage_only_rel_l2=e_floor))
+    assert e_floor > 1e-3 and e_hip < 1.15 * e_floor, (e_hip, e_floor)

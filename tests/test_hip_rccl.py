@@ -134,3 +134,33 @@ def test_bench_two_ranks_on_one_device(endpoints, workload):
     assert n == (16 if workload == "seq16" else 7)
     # replicate: ceil(interior / 2) owned + the 2 end points; exchange: owned frames only
     assert cfg["max_local_batch"] == ((n - 2 + 1) // 2 + 2 if endpoints == "replicate" else (n + 1) // 2)
+
+
+def _run_ranks(n, one_device):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **({"AID_RANKS_ONE_DEVICE": "1"} if one_device else {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "helpers", "rccl_ranks.py")]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    tb = "\n".join(ln for ln in p.stderr.splitlines() if ln.startswith("[rank"))          # the ranks' own tracebacks
+    assert p.returncode == 0, tb or p.stderr[-3000:]
+    assert sorted(ln for ln in p.stdout.splitlines() if ln.startswith("OK ")) == sorted(f"OK {r}" for r in range(n))
+
+
+def test_rank_program_two_ranks_on_one_device():
+    """The rank program of the multi-GPU test below, two rank processes on cuda:0 over gloo: keeps it correct on the 1-GPU boxes."""
+    _run_ranks(2, one_device=True)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the first multi-GPU lease runs it unattended")
+def test_rccl_real_ranks_broadcast_gather_and_endpoint_exchange():
+    """RCCL with MORE than one rank — broadcast_conditioning, gather_owned of both shard layouts and the per-layer
+    end-point hand-over (dist.EndpointExchange) on real rank processes, one per visible GPU (up to 8), launched the way the driver
+    launches bench.py.  Skipped on the 1-GPU boxes this repository has been developed on; tests/helpers/rccl_ranks.py is the rank program."""
+    _run_ranks(min(torch.cuda.device_count(), 8), one_device=False)

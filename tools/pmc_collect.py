@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Collect rocprofv3 PMC counters per launch of every aid_* kernel of the bench workloads -> profiles/r04_pmc.json.
+"""Collect rocprofv3 PMC counters per launch of every aid_* kernel of the bench workloads -> profiles/r05_pmc.json.
 
 Procedure (MI355X_MICROARCH.md, HBM / PMC-slot sections): every counter group is its OWN rocprofv3 pass with
 --kernel-trace only (never combined with sys / hip / memory-copy tracing), over
@@ -48,7 +48,7 @@ def bench_name(sym):
     m = re.search(r"aid_attn_short_kernelIDF16b?_?Li(\d+)ELi(\d)", sym)
     if m:
         return f"aid_attn_short<{dt},d{m.group(1)},{MODES[m.group(2)]}>"
-    for k in ("aid_gemm_nt_ppx_kernel", "aid_gemm_nt_pp_kernel", "aid_gemm_nt_pipe_kernel", "aid_gemm_nt_kernel", "aid_lerp_kv_kernel",
+    for k in ("aid_gemm_rs_kernel", "aid_gemm_nt_ppx_kernel", "aid_gemm_nt_pp_kernel", "aid_gemm_nt_pipe_kernel", "aid_gemm_nt_kernel", "aid_lerp_kv_kernel",
               "aid_layernorm_kernel", "aid_ln_stats_kernel"):
         if k in sym:
             short = {"aid_lerp_kv_kernel": "aid_lerp_kv", "aid_layernorm_kernel": "aid_layernorm", "aid_ln_stats_kernel": "aid_ln_stats"}
@@ -114,7 +114,7 @@ def main():
         return
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     wls = sys.argv[sys.argv.index("--workloads") + 1].split(",") if "--workloads" in sys.argv else ["sdxl", "sd15"]
-    out = argv[0] if argv else os.path.join(ROOT, "profiles", "r04_pmc.json")
+    out = argv[0] if argv else os.path.join(ROOT, "profiles", "r05_pmc.json")
     res = {"_comment": __doc__.split("usage")[0].strip(), "models": {}}
     for wl in wls:
         merged = collections.defaultdict(dict)

@@ -1,9 +1,9 @@
-# Re-create the round's measurement set on the GPU box (run from the repo root under gpurun); results land in gpurun_out/r04/
-# and are copied to profiles/r04_* after review:  bench lines, rocprofv3 kernel-trace summaries of the SAME commands, the PMC
+# Re-create the round's measurement set on the GPU box (run from the repo root under gpurun); results land in gpurun_out/r05/
+# and are copied to profiles/r05_* after review:  bench lines, rocprofv3 kernel-trace summaries of the SAME commands, the PMC
 # collection (tools/pmc_collect.py), the per-launch breakdown of both stacks, the projection microbenchmark, the attention
 # A/B table of the knobs that decide the variants, the sublayer modes.
 set -x
-R=gpurun_out/r04; mkdir -p $R
+R=gpurun_out/r05; mkdir -p $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $R/bench_default.json 2> $R/bench_default.err
 timeout 400 python bench.py --workload ip --steps 20 --warmup 5 > $R/bench_ip.json 2> $R/bench_ip.err
 timeout 400 python bench.py --workload seq16 --steps 20 --warmup 5 --no-cpu-baseline > $R/bench_seq16.json 2> $R/bench_seq16.err
@@ -20,6 +20,7 @@ python tools/kbench_proj.py > $R/kbench_proj.txt 2>/dev/null
 python tools/kbench_attn_ab.py "ATTN_V2=-1" "ATTN_V2=0" --rounds 5 --iters 6 --shapes sdxl --inner > $R/kbench_attn.txt 2>/dev/null
 python tools/dev/xs_ab.py > $R/xs_ab.txt 2>/dev/null
 python tools/gemm_ab.py "GEMM_TRI=0,GEMM_PP=0" "GEMM_TRI=0,GEMM_PP=1" "GEMM_TRI=-1,GEMM_PP=1" --rounds 5 --iters 10 --torch > $R/gemm_ab.txt 2>/dev/null
+python tools/gemm_ab.py "GEMM_RS=0" "GEMM_RS=-1" "GEMM_RS=1" --short --rounds 5 --iters 10 > $R/gemm_rs_ab.txt 2>/dev/null
 for u in mfma_cadence store_bw valu_rate barrier_cost wave_simd; do
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip
   ./tools/ubench/$u > $R/ubench_$u.txt 2>&1
@@ -28,7 +29,7 @@ done
     AID_LN_FOLD=$2 python bench.py --workload $wl --sublayers $1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-also 2>/dev/null | tail -1 |
       python -c "import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], 'sublayers=' + sys.argv[2], 'AID_LN_FOLD=' + sys.argv[3], 'frames/s', round(d['value'], 3), 'ms/step', round(d['ms_per_step'], 3))" $wl $1 $2
   done; done ) > $R/sublayers.txt
-cp profiles/r04_depth_parity.json gpurun_out/depth_parity.json 2>/dev/null    # (keeps the *_fullwidth entries of the AID_E2E_FULL_WIDTH=1 run)
+cp profiles/r05_depth_parity.json gpurun_out/depth_parity.json 2>/dev/null    # (keeps the *_fullwidth entries of the AID_E2E_FULL_WIDTH=1 run)
 AID_WRITE_MEASUREMENTS=1 python -m pytest tests/test_hip_depth_and_pipelines.py -m gpu -q > $R/depth_pytest.log 2>&1; cp gpurun_out/depth_parity.json $R/ 2>/dev/null
 timeout 1500 python tools/pmc_collect.py $R/pmc.json > $R/pmc.log 2>&1
 tail -5 $R/pmc.log
