@@ -70,18 +70,18 @@ struct ProfScope {          // records an event pair around one launch when prof
 
 // ---- tuning knobs (aid_kernels.hpp: enum Tune) -----------------------------------------------------
 const char* const g_tune_names[aid::TUNE_COUNT] = {"GEMM_VARIANT", "GEMM_PP", "GEMM_TRI", "ATTN_NW", "ATTN_QB", "ATTN_PIPE",
-                                                   "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2", "CU_SHARE", "GEMM_RS"};
+                                                   "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2", "CU_SHARE", "GEMM_RS", "ATTN_TX", "ATTN_TX_TILES"};
 // Largest value a knob accepts.  Every accepted value selects between kernels / launch shapes that compute THE SAME RESULT (the parity
 // suite runs under each of them); values beyond the range are refused by aid_set_tuning and ignored in the environment.  The timing
 // ablations (kernels that skip work, "results are garbage") exist only in development builds (-DAID_ABLATIONS, tools/dev/Makefile ->
 // tools/dev/libaid_abl.so) and are addressed through the same table there.
 #ifdef AID_ABLATIONS
-const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1, 8, 1};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1, 8, 1, 1, 64};
 #else
 #ifdef AID_RS_VARIANTS
-const int g_tune_max[aid::TUNE_COUNT] = {31, 7, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 7, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64};
 #else
-const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64};
 #endif
 #endif
 struct TuneTable {
@@ -448,6 +448,20 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     // kernel can run the whole call (aid_attn_xs.hip).  NOT the default: measured 5 - 20 % slower than aid_attn_kernel on the stacks'
     // 77-key launches (a 256-row item is two tiles long — its per-item cost is as large as its work; profiles/r04_attn_notes.txt);
     // ATTN_V2 = 1 selects it (parity suite tests/test_hip_attn_short.py)
+    // text keys (<= 96 per segment, the cross-attention of the SDXL stack): every segment resident in LDS, independent waves, exact
+    // two-pass softmax per segment (aid_attn_tx.hip).  NOT the default: 5 - 16 % faster than aid_attn_kernel launch by launch, 0.1 %
+    // in the stack (profiles/r05_attn_tx_notes.txt: three differently built kernels all sit at 2x the HBM time of these launches);
+    // ATTN_TX = 1 selects it (parity suite tests/test_hip_attn_tx.py)
+    if (aid::tune(aid::TUNE_ATTN_TX) == 1 && v2 != 1 && aid::attn_tx_supported(a)) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "aid_attn_tx<%s,d64,%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.mode == AID_MODE_OUTER ? "outer" : "plain");
+        {
+            ProfScope ps(static_cast<hipStream_t>(stream), nm, flops, bytes, flops_exec);
+            e = aid::attn_tx_launch(a, static_cast<hipStream_t>(stream));
+        }
+        g_variant = a.mode == AID_MODE_OUTER ? "aid_attn_tx<d64,outer>" : "aid_attn_tx<d64,plain>";
+        return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
+    }
     if (v2 == 1 && aid::attn_xs_supported(a)) {
         char nm[64];
         snprintf(nm, sizeof(nm), "aid_attn_xs<%s,d64%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.mode == AID_MODE_OUTER ? ",outer" : "");

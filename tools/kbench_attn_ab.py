@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-process interleaved A/B of attention-kernel variants (development knobs read per call by the library) at the
 launch shapes of the two bench stacks: 7 AID frames + 7 plain riders, BetaPPF(50, 50) coefficients.
-usage: python tools/kbench_attn_ab.py "AID_ATTN_QB=1" "AID_ATTN_QB=2" [--rounds 5] [--iters 6] [--shapes sdxl,sd15]
+usage: python tools/kbench_attn_ab.py "AID_ATTN_QB=1" "AID_ATTN_QB=2" [--rounds 5] [--iters 6] [--shapes sdxl,sd15] [--only "S1024 x77"]
 Prints per shape and variant: median us per launch over the rounds, algorithmic and executed TFLOP/s."""
 import os
 import statistics
@@ -47,8 +47,11 @@ def one(fn):
             "+".join(x.kernel.decode().replace("aid_attn", "") for x in e[:per]))
 
 
+ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""       # substring of the shape tag
 for grp in which:
     for tag, dt, s, l, h, d, modes in SHAPES[grp]:
+        if ONLY not in tag:
+            continue
         n, c = 7, h * d
         q = torch.randn(2 * n, s, c, device=dev).to(dt)
         k = torch.randn(2 * n, l, c, device=dev).to(dt)
@@ -59,6 +62,8 @@ for grp in which:
         coef = torch.tensor(vals, device=dev)
         out = torch.empty_like(q)
         for mode in modes:
+            if "--mode" in sys.argv and sys.argv[sys.argv.index("--mode") + 1] != mode:
+                continue
             fused = mode != "plain"
             segx = ops.executed_segments(mode, fused, vals, 2 * n, None, 0, n - 1)
             fn = lambda: ops.attn_fwd(q, k, vt, h, l=l, mode=mode, fused=fused, coef=coef if fused else None,      # noqa: E731
@@ -66,7 +71,7 @@ for grp in which:
             res = {i: [] for i in range(len(variants))}
             names = {}
             def apply(v):                                     # knobs are set through the library (aid_set_tuning), not the environment
-                for name in ("ATTN_NW", "ATTN_QB", "ATTN_PIPE", "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2"):
+                for name in ("ATTN_NW", "ATTN_QB", "ATTN_PIPE", "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2", "ATTN_TX", "ATTN_TX_TILES"):
                     ops.set_tuning(name, int(v.get(name, v.get("AID_" + name, -1))))
             for i, v in enumerate(variants):                  # warm every variant (lazy attributes)
                 apply(v); fn(); fn()
