@@ -77,6 +77,12 @@ __device__ __forceinline__ float tx_dot2<f16>(uint32_t w, float acc) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), one, acc, false);
 }
 
+#if defined(AID_TX_ABL) && AID_TX_ABL == 2
+#define TX_EXP(x) (x)                               // development: no exponentials (garbage results, timing only)
+#else
+#define TX_EXP(x) __builtin_amdgcn_exp2f(x)
+#endif
+
 // NSEG = LDS regions: 1 for PLAIN launches, 3 for OUTER launches (whose frames run one to three segments each).
 template <typename T, int NSEG>
 __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams p) {
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
     const int per = a.n_frames * p.chunks;
     const int id = heavy_first((int)blockIdx.x, (int)gridDim.x, p.na, per);
     const int head = id / per, rem = id - head * per, fr = rem / p.chunks, chunk = rem - fr * p.chunks;
-    const int L = a.l;
+    const int Lk = a.l;
     const int kvf = a.kv_map ? a.kv_map[fr] : fr;
     const float cf = (NSEG == 1 || a.coef == nullptr) ? -1.f : a.coef[fr];
     // which segments this frame runs — the same decisions as aid_attn_kernel (see there): single = PLAIN, a rider (negative
@@ -110,16 +116,17 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
     const int t_end = t0 + p.tiles_per_chunk < ntiles ? t0 + p.tiles_per_chunk : ntiles;
 
     auto load_q = [&](T8 (&q)[4], int t) {
-        const int row = 32 * t + m;
+        const int row = 32 * t + m < a.s ? 32 * t + m : a.s - 1;       // rows past S: any valid row, their results are not stored
         const T* src = Qg + (int64_t)row * a.ldq;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = row < a.s ? *reinterpret_cast<const T8*>(src + 16 * j) : zero8<T>();
+        for (int j = 0; j < 4; ++j) q[j] = *reinterpret_cast<const T8*>(src + 16 * j);
     };
     T8 qf[4];
     int t = t0 + wave;
     if (t < t_end) load_q(qf, t);                       // in flight across the fill
 
     // ---- fill: every segment of this (frame, head), once per workgroup ------------------------------------------------------------
+#if !defined(AID_TX_ABL) || AID_TX_ABL != 1
     {
         const T* Kg = reinterpret_cast<const T*>(a.k) + head * 64;
         const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)(head * 64) * a.ldvt;
@@ -133,12 +140,12 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
             for (int i = 0; i < 3; ++i) {
                 const int idx = tid + 256 * i;
                 const int key = idx >> 3, c = idx & 7;              // K: 8 consecutive lanes = one 128-B key row of the head
-                stk[r][i] = key < L ? *reinterpret_cast<const T8*>(kb + (int64_t)key * a.ldk + 8 * c) : zero8<T>();
+                stk[r][i] = key < Lk ? *reinterpret_cast<const T8*>(kb + (int64_t)key * a.ldk + 8 * c) : zero8<T>();
                 const int ch = idx / 12, x = idx - 12 * ch;         // V^T: 12 consecutive lanes = the 96 keys of one channel
-                T8 v = 8 * x < L ? *reinterpret_cast<const T8*>(vb + (int64_t)ch * a.ldvt + 8 * x) : zero8<T>();
+                T8 v = 8 * x < Lk ? *reinterpret_cast<const T8*>(vb + (int64_t)ch * a.ldvt + 8 * x) : zero8<T>();
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (8 * x + e >= L) v[e] = (T)0.0f;             // keys >= L get P = 0; their V must be finite
+                    if (8 * x + e >= Lk) v[e] = (T)0.0f;             // keys >= L get P = 0; their V must be finite
                 stv[r][i] = v;
             }
         }
@@ -162,24 +169,34 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
             }
         }
     }
+#endif
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qf[j]));      // the first tile's Q has landed (the fill waited on the same counter)
 
-    const int nkt = (L + 31) >> 5;                                   // score tiles that hold a valid key
+    const int nkt = (Lk + 31) >> 5;                                  // score tiles that hold a valid key
     const float c2 = p.c2;
     const float osc = a.out_scale * (a.frame_scale ? a.frame_scale[fr] : 1.f);
     const unsigned char* kfrag0 = tx_smem + (h * TXK + m) * 16;                    // + region, + j * 3072 + kt * 512
     const unsigned char* vfrag0 = tx_smem + TX_KBYTES + (h * 64 + m) * 16;         // + region, + (4 kt + 2 s) * 1024 + ct * 512
-    const int lim = L - 4 * h;                                       // register i of tile kt is a valid key iff 32 kt + 8 (i / 4) + i % 4 < lim
+    const int lim = Lk - 4 * h;                                      // register i of tile kt is a valid key iff 32 kt + 8 (i / 4) + i % 4 < lim
 
     for (; t < t_end; t += 4) {
         T8 qn[4];
         const bool more = t + 4 < t_end;
         if (more) load_q(qn, t + 4);
 
+        int L = Lk;
+        asm volatile("" : "+s"(L));        // the per-half-tile decisions are re-derived per tile (scalar compares) instead of living in spilled SGPR pairs
         f32x16 o_own[2], res[2] = {tx_zero16(), tx_zero16()};
         float m_own = 0.f, l_own = 1.f;
+#if defined(AID_TX_ABL) && AID_TX_ABL == 3            // development: no arithmetic at all — the kernel as a copy of its q rows
+        for (int j = 0; j < 4; ++j) { const u32x4 w = __builtin_bit_cast(u32x4, qf[j]); for (int e = 0; e < 4; ++e) res[j >> 1][4 * (j & 1) + e] = __uint_as_float(w[e]); }
+        for (int sg = 0; sg < 0; ++sg) {
+#else
 #pragma unroll 1
         for (int sg = 0; sg < nseg; ++sg) {
+#endif
             const unsigned char* kf = kfrag0 + sg * TX_REGION;
             const unsigned char* vf = vfrag0 + sg * TX_REGION;
             // ---- scores of the whole segment: S^T[key, row] = K Q^T ----
@@ -191,47 +208,50 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc = mfma32(*reinterpret_cast<const T8*>(kf + j * 3072 + kt * 512), qf[j], acc);
-                    if (32 * kt + 32 > L) {
+                    // the 16-key half that straddles L: keys >= L to -inf.  Halves entirely past L are never read again.
 #pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (32 * kt + 8 * (i >> 2) + (i & 3) >= lim) acc[i] = -INFINITY;
-                    }
+                    for (int s = 0; s < 2; ++s)
+                        if (32 * kt + 16 * s < L && 32 * kt + 16 * s + 16 > L) {
+#pragma unroll
+                            for (int i = 8 * s; i < 8 * s + 8; ++i)
+                                if (32 * kt + 8 * (i >> 2) + (i & 3) >= lim) acc[i] = -INFINITY;
+                        }
                     sc[kt] = acc;
                 }
             }
-            // ---- one maximum per row (the lane's 16 keys per tile, then the other half of the wave) ----
+            // ---- one maximum per row (the lane's 8 keys per valid half tile, then the other half of the wave) ----
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt)
-                if (kt < nkt) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
-                }
+                for (int s = 0; s < 2; ++s)
+                    if (32 * kt + 16 * s < L) {
+#pragma unroll
+                        for (int i = 8 * s; i < 8 * s + 8; ++i) mx = fmaxf(mx, sc[kt][i]);
+                    }
             mx = max_halves(mx);
             const float nm = -mx * c2;
             // ---- probabilities, row sum (of the rounded values the second product uses), O^T = V^T P^T ----
             f32x16 oc[2] = {tx_zero16(), tx_zero16()};
             float ls = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) {
-                if (kt < nkt) {
-                    uint32_t pk[8];
+            for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[kt][2 * u], c2, nm));
-                        const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[kt][2 * u + 1], c2, nm));
-                        pk[u] = tx_pack2<T>(p0, p1);
-                        ls = tx_dot2<T>(pk[u], ls);
-                    }
+                for (int s = 0; s < 2; ++s)
+                    if (32 * kt + 16 * s < L) {
+                        uint32_t pk[4];
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const T8 pf = __builtin_bit_cast(T8, (u32x4){pk[4 * s], pk[4 * s + 1], pk[4 * s + 2], pk[4 * s + 3]});
+                        for (int u = 0; u < 4; ++u) {
+                            const float p0 = TX_EXP(fmaf(sc[kt][8 * s + 2 * u], c2, nm));
+                            const float p1 = TX_EXP(fmaf(sc[kt][8 * s + 2 * u + 1], c2, nm));
+                            pk[u] = tx_pack2<T>(p0, p1);
+                            ls = tx_dot2<T>(pk[u], ls);
+                        }
+                        const T8 pf = __builtin_bit_cast(T8, (u32x4){pk[0], pk[1], pk[2], pk[3]});
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct)
                             oc[ct] = mfma32(*reinterpret_cast<const T8*>(vf + (4 * kt + 2 * s) * 1024 + ct * 512), pf, oc[ct]);
                     }
-                }
-            }
             ls = sum_halves(ls);
             // ---- combine ----
             const int rl = NSEG == 1 ? 0 : sg == 0 ? role0 : sg == 1 ? role1 : 2;
@@ -258,24 +278,35 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
             }
         }
 
-        // ---- store: lane (row m, half h) holds channels 32 ct + 8 g + 4 h + {0..3}; after the swaps 32 ct + 16 u + 8 h + {0..7} ----
+        // ---- output words: lane (row m, half h) holds channels 32 ct + 8 g + 4 h + {0..3}; after the swaps 32 ct + 16 u + 8 h + {0..7} ----
+        u32x4 ow[4];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t x0 = tx_pack2<T>(res[ct][8 * u], res[ct][8 * u + 1]), x1 = tx_pack2<T>(res[ct][8 * u + 2], res[ct][8 * u + 3]);
+                const uint32_t y0 = tx_pack2<T>(res[ct][8 * u + 4], res[ct][8 * u + 5]), y1 = tx_pack2<T>(res[ct][8 * u + 6], res[ct][8 * u + 7]);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                ow[2 * ct + u] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+            }
+        // ORDER MATTERS (loads and stores share vmcnt on gfx950 and the compiler waits for both at once): the next tile's Q — requested
+        // before this tile's arithmetic — is waited for HERE, before this tile's stores are issued, so that wait covers loads that had
+        // the whole tile to land and stores that are a whole tile old; the stores below then have the next tile to complete.
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qf[j] = qn[j];
+                asm volatile("" : "+v"(qf[j]));
+            }
+        }
         {
             const int row = 32 * t + m;
             T* dst = Og + (int64_t)row * a.ldo;
+            if (row < a.s) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const uint32_t x0 = tx_pack2<T>(res[ct][8 * u], res[ct][8 * u + 1]), x1 = tx_pack2<T>(res[ct][8 * u + 2], res[ct][8 * u + 3]);
-                    const uint32_t y0 = tx_pack2<T>(res[ct][8 * u + 4], res[ct][8 * u + 5]), y1 = tx_pack2<T>(res[ct][8 * u + 6], res[ct][8 * u + 7]);
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-                    if (row < a.s) *reinterpret_cast<u32x4*>(dst + 32 * ct + 16 * u) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
-                }
-        }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) qf[j] = qn[j];
+                for (int w = 0; w < 4; ++w) *reinterpret_cast<u32x4*>(dst + 16 * w) = ow[w];
+            }
         }
     }
 }
