@@ -444,32 +444,19 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     const bool alone = a.mode == AID_MODE_PLAIN || (a.l % 512 == 0 && (a.mode == AID_MODE_OUTER || (a.k2 && a.vt2)));
     const bool dflt = a.l >= ((a.mode == AID_MODE_PLAIN || (a.mode == AID_MODE_OUTER && !a.fused)) ? 2048 : 1024);
     const int v2 = aid::tune(aid::TUNE_ATTN_V2);
-    // short key streams with padded keys / values (the cached text keys of cross-attention, l = 77): the short-stream ping-pong
-    // kernel can run the whole call (aid_attn_xs.hip).  NOT the default: measured 5 - 20 % slower than aid_attn_kernel on the stacks'
-    // 77-key launches (a 256-row item is two tiles long — its per-item cost is as large as its work; profiles/r04_attn_notes.txt);
-    // ATTN_V2 = 1 selects it (parity suite tests/test_hip_attn_short.py)
-    // text keys (<= 96 per segment, the cross-attention of the SDXL stack): every segment resident in LDS, independent waves, exact
-    // two-pass softmax per segment (aid_attn_tx.hip).  NOT the default: 5 - 16 % faster than aid_attn_kernel launch by launch, 0.1 %
-    // in the stack (profiles/r05_attn_tx_notes.txt: three differently built kernels all sit at 2x the HBM time of these launches);
-    // ATTN_TX = 1 selects it (parity suite tests/test_hip_attn_tx.py)
-    if (aid::tune(aid::TUNE_ATTN_TX) == 1 && v2 != 1 && aid::attn_tx_supported(a)) {
+    // text keys (<= 96 per segment: the cross-attention of the SDXL stack): every segment resident in LDS, independent waves, online
+    // softmax over the segment's <= 3 score tiles, OUTER sides combined from the segments' maxima and row sums (aid_attn_tx.hip).  The
+    // default wherever it applies (profiles/r05_attn_tx_notes.txt); ATTN_TX = 0 keeps these calls on aid_attn_kernel.  (Round 4's
+    // short-stream ping-pong kernel, aid_attn_xs.hip, measured 5 - 20 % slower than aid_attn_kernel and was removed in round 5.)
+    if (aid::tune(aid::TUNE_ATTN_TX) != 0 && v2 != 1 && aid::attn_tx_supported(a)) {
         char nm[64];
-        snprintf(nm, sizeof(nm), "aid_attn_tx<%s,d64,%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.mode == AID_MODE_OUTER ? "outer" : "plain");
+        static const char* const mn[] = {"plain", "inner", "outer"};
+        snprintf(nm, sizeof(nm), "aid_attn_tx<%s,d64,%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", mn[a.mode]);
         {
             ProfScope ps(static_cast<hipStream_t>(stream), nm, flops, bytes, flops_exec);
             e = aid::attn_tx_launch(a, static_cast<hipStream_t>(stream));
         }
-        g_variant = a.mode == AID_MODE_OUTER ? "aid_attn_tx<d64,outer>" : "aid_attn_tx<d64,plain>";
-        return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
-    }
-    if (v2 == 1 && aid::attn_xs_supported(a)) {
-        char nm[64];
-        snprintf(nm, sizeof(nm), "aid_attn_xs<%s,d64%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.mode == AID_MODE_OUTER ? ",outer" : "");
-        {
-            ProfScope ps(static_cast<hipStream_t>(stream), nm, flops, bytes, flops_exec);
-            e = aid::attn_xs_launch(a, static_cast<hipStream_t>(stream));
-        }
-        g_variant = a.mode == AID_MODE_OUTER ? "aid_attn_xs<d64,outer>" : "aid_attn_xs<d64>";
+        g_variant = a.mode == AID_MODE_OUTER ? "aid_attn_tx<d64,outer>" : a.mode == AID_MODE_INNER ? "aid_attn_tx<d64,inner>" : "aid_attn_tx<d64,plain>";
         return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
     }
     const bool use_pp = aid::attn_pp_supported(a) && (alone || n_single > 0) &&
@@ -633,7 +620,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     at.s = a.s; at.l = l; at.heads = a.heads; at.d = d;
     at.ldq = a.c; at.ldk = a.c; at.ldvt = cv.lp; at.ldo = a.c;
     at.q_fs = (int64_t)a.s * a.c; at.k_fs = (int64_t)l * a.c; at.vt_fs = (int64_t)a.c * cv.lp; at.o_fs = (int64_t)a.s * a.c;
-    if (cached && a.kv_cached_lt > 0) {        // keys / values padded to whole tiles by the caller (short-stream ping-pong kernel)
+    if (cached && a.kv_cached_lt > 0) {        // keys / values padded to whole tiles by the caller (an accepted layout; no kernel needs it)
         at.ldvt = a.kv_cached_lt;
         at.k_fs = (int64_t)a.kv_cached_lt * a.c; at.vt_fs = (int64_t)a.c * a.kv_cached_lt;
         at.kv_padded = 1;

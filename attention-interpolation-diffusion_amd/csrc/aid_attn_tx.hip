@@ -1,25 +1,26 @@
 // Attention over TEXT keys, head dim 64: the cross-attention calls of the SDXL stack (77 keys per context; reference
 // interpolation.py:623-664 with encoder_hidden_states given, :581-584 de-activated) — PLAIN calls, the PLAIN riders of a batched-CFG
-// call, and the one / two / three key segments of a pure or fused OUTER frame.
+// call, and the one / two / three key segments of a pure or fused OUTER frame.  The default for these calls since round 5.
 //
-// Why a third kernel.  These launches move 37 - 147 MB of q / out per call against 10 GFLOP of arithmetic: they are HBM streams
-// (tools/ubench/head_stride_copy.hip: a per-head copy of the same rows in the same order runs at 4.8 - 6.0 TB/s = 12 - 15 us for the
-// S = 1024 call).  aid_attn_kernel runs them as 2240 - 4480 short workgroups, each one latency chain (28 us plain, 45 us fused OUTER),
-// aid_attn_xs.hip as one ping-pong tile stream whose per-item skeleton is as long as a two-tile item (5 - 20 % slower still).  What
-// both pay for is machinery for LONG key streams: tile rings, barriers per tile, an online softmax that rescales the output block.
-// With at most 96 keys per segment none of it is needed:
+// These launches move 37 - 147 MB of q / out per call against 10 GFLOP of arithmetic: they are HBM streams (tools/ubench/
+// head_stride_copy.hip: a per-head copy of the same rows in the same order runs at 4.8 - 6.0 TB/s = 12 - 15 us for the S = 1024 call).
+// aid_attn_kernel runs them as 2240 - 4480 short workgroups, each one latency chain behind machinery made for LONG key streams (tile
+// rings, a barrier per tile); with at most 96 keys per segment none of that is needed:
 //   * every key segment of the workgroup's (frame, head) sits in LDS for the workgroup's whole life (24 KB per segment: K as
 //     [8 chunks][96 keys] x 16 B, V^T as [12 chunks][64 channels] x 16 B — fragment reads are consecutive 16-B words over the lanes,
 //     conflict-free without padding; three segments = 72 KB, two workgroups per CU); ONE barrier per workgroup;
 //   * a wave owns 32 query rows at a time and is independent of the other waves from then on: Q fragments straight from global
-//     memory (the next tile's are requested before the current tile is computed), scores of a whole segment in registers (3 tiles x 16),
-//     ONE maximum, exponentials, row sum, P V — an exact two-pass softmax per segment, no rescaling of anything;
+//     memory (the next tile's are requested before the current tile is computed and waited for BEFORE the current tile's stores are
+//     issued: loads and stores share vmcnt), one 32-key score tile at a time with an online softmax over the segment's <= 3 tiles
+//     (16 score registers: 120 VGPRs = four waves per SIMD for PLAIN launches, 218 and no scratch for OUTER ones), 16-key halves past
+//     L skipped;
 //   * the segments of a fused OUTER frame are combined at the end from their maxima and row sums:
 //         out = (1 - c) [a1 O_own + b1 O_beg] / (a1 l_own + b1 l_beg) + c [a2 O_own + b2 O_end] / (a2 l_own + b2 l_end),
 //         a1 = 2^(m_own - max(m_own, m_beg)), b1 = 2^(m_beg - max(m_own, m_beg)), ... — the same softmax over [own ; begin] and
 //         [own ; end] as the reference's two calls, with the own keys' scores and products computed once;
 //   * the 32 x 64 output block leaves as 16-byte stores (two v_permlane32_swap per 16 channels bring the halves of a row together).
-// Waves overlap each other's phases (global latency, MFMA, VALU) by being many: 8 per CU, no wave ever waits for another.
+// Measured -5 ... -17 % against aid_attn_kernel launch by launch; what still separates it from the copy's time is in
+// profiles/r05_attn_tx_notes.txt (ablation builds: -DAID_TX_ABL=1 no fill, 2 no exponentials, 3 no arithmetic at all).
 #include <string.h>
 
 #include "aid_common.hpp"
@@ -100,14 +101,29 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
     // coefficient) or a fused END-POINT frame; coefficient exactly 0 / 1 skips the zero-weighted side
     const bool single = NSEG == 1 || cf < 0.f || (a.fused && ((cf == 0.f && kvf == a.begin) || (cf == 1.f && kvf == a.end)));
     const bool has_own = single || a.fused != 0;
-    const bool has_b = !single && cf != 1.f, has_e = !single && cf != 0.f;
+    // INNER: ONE interpolated segment [(1 - c) K_begin + c K_end] beside the own keys, one softmax over both — the "begin side" with
+    // weight 1; its keys / values are the end-point frame itself for c = 0 / 1, else the rows aid_lerp_kv wrote to k2 / vt2
+    const bool inner = NSEG > 1 && a.mode == AID_MODE_INNER;
+    const bool has_b = !single && (inner || cf != 1.f), has_e = !single && !inner && cf != 0.f;
     const int nseg = (has_own ? 1 : 0) + (has_b ? 1 : 0) + (has_e ? 1 : 0);
-    // role of region r: 0 own, 1 begin side, 2 end side; source frame of its keys / values (-1: region unused)
+    // role of region r: 0 own, 1 begin side, 2 end side; source of its keys / values (nullptr: region unused)
     const int role0 = has_own ? 0 : has_b ? 1 : 2;
     const int role1 = has_own ? (has_b ? 1 : 2) : 2;
-    const int srcf[3] = {has_own ? kvf : has_b ? a.begin : a.end,
-                         nseg < 2 ? -1 : (has_own && has_b) ? a.begin : a.end,
-                         nseg < 3 ? -1 : a.end};
+    const T* const Kh = reinterpret_cast<const T*>(a.k) + head * 64;
+    const T* const Vh = reinterpret_cast<const T*>(a.vt) + (int64_t)(head * 64) * a.ldvt;
+    const bool lerped = inner && cf != 0.f && cf != 1.f;
+    const T* const kside = lerped ? reinterpret_cast<const T*>(a.k2) + head * 64 + (int64_t)fr * a.k_fs
+                                  : Kh + (int64_t)((inner ? cf == 1.f : !has_b) ? a.end : a.begin) * a.k_fs;
+    const T* const vside = lerped ? reinterpret_cast<const T*>(a.vt2) + (int64_t)(head * 64) * a.ldvt + (int64_t)fr * a.vt_fs
+                                  : Vh + (int64_t)((inner ? cf == 1.f : !has_b) ? a.end : a.begin) * a.vt_fs;
+    // region 0: own keys, or the first side of a pure call; region 1: the first (or only) side behind own keys, or the end side of a
+    // pure OUTER call; region 2: the end side of a fused OUTER frame
+    const T* const rk[3] = {has_own ? Kh + (int64_t)kvf * a.k_fs : kside,
+                            nseg < 2 ? nullptr : has_own ? kside : Kh + (int64_t)a.end * a.k_fs,
+                            nseg < 3 ? nullptr : Kh + (int64_t)a.end * a.k_fs};
+    const T* const rv[3] = {has_own ? Vh + (int64_t)kvf * a.vt_fs : vside,
+                            nseg < 2 ? nullptr : has_own ? vside : Vh + (int64_t)a.end * a.vt_fs,
+                            nseg < 3 ? nullptr : Vh + (int64_t)a.end * a.vt_fs};
 
     const T* Qg = reinterpret_cast<const T*>(a.q) + (int64_t)fr * a.q_fs + head * 64 + 8 * h;
     T* Og = reinterpret_cast<T*>(a.out) + (int64_t)fr * a.o_fs + head * 64 + 8 * h;
@@ -128,14 +144,12 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
     // ---- fill: every segment of this (frame, head), once per workgroup ------------------------------------------------------------
 #if !defined(AID_TX_ABL) || AID_TX_ABL != 1
     {
-        const T* Kg = reinterpret_cast<const T*>(a.k) + head * 64;
-        const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)(head * 64) * a.ldvt;
         T8 stk[NSEG][3], stv[NSEG][3];
 #pragma unroll
         for (int r = 0; r < NSEG; ++r) {
-            if (srcf[r] < 0) continue;
-            const T* kb = Kg + (int64_t)srcf[r] * a.k_fs;
-            const T* vb = Vg + (int64_t)srcf[r] * a.vt_fs;
+            if (rk[r] == nullptr) continue;
+            const T* kb = rk[r];
+            const T* vb = rv[r];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int idx = tid + 256 * i;
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
         }
 #pragma unroll
         for (int r = 0; r < NSEG; ++r) {
-            if (srcf[r] < 0) continue;
+            if (rk[r] == nullptr) continue;
             unsigned char* reg = tx_smem + r * TX_REGION;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -199,59 +213,62 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
 #endif
             const unsigned char* kf = kfrag0 + sg * TX_REGION;
             const unsigned char* vf = vfrag0 + sg * TX_REGION;
-            // ---- scores of the whole segment: S^T[key, row] = K Q^T ----
-            f32x16 sc[3];
+            // ---- one 32-key score tile at a time: S^T[key, row] = K Q^T, running maximum, probabilities, O^T += V^T P^T ----
+            // (online softmax over the <= 3 tiles of the segment: 16 score registers live instead of 48 — that is what lets the PLAIN
+            //  instantiation run four waves per SIMD and the OUTER one keep its three output blocks without scratch; the output block
+            //  is rescaled only when a later tile raises a row's maximum)
+            f32x16 oc[2] = {tx_zero16(), tx_zero16()};
+            float mx = -INFINITY, ls = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
                 if (kt < nkt) {
-                    f32x16 acc = tx_zero16();
+                    f32x16 sc = tx_zero16();
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc = mfma32(*reinterpret_cast<const T8*>(kf + j * 3072 + kt * 512), qf[j], acc);
-                    // the 16-key half that straddles L: keys >= L to -inf.  Halves entirely past L are never read again.
+                        sc = mfma32(*reinterpret_cast<const T8*>(kf + j * 3072 + kt * 512), qf[j], sc);
+                    // the 16-key half that straddles L: keys >= L to -inf.  Halves entirely past L are never read.
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
                         if (32 * kt + 16 * s < L && 32 * kt + 16 * s + 16 > L) {
 #pragma unroll
                             for (int i = 8 * s; i < 8 * s + 8; ++i)
-                                if (32 * kt + 8 * (i >> 2) + (i & 3) >= lim) acc[i] = -INFINITY;
+                                if (32 * kt + 8 * (i >> 2) + (i & 3) >= lim) sc[i] = -INFINITY;
                         }
-                    sc[kt] = acc;
+                    float tm = -INFINITY;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        if (32 * kt + 16 * s < L) {
+#pragma unroll
+                            for (int i = 8 * s; i < 8 * s + 8; ++i) tm = fmaxf(tm, sc[i]);
+                        }
+                    tm = max_halves(tm);
+                    if (kt > 0 && __any(tm > mx)) {                       // a row's maximum rises: rescale what was accumulated
+                        const float mn = fmaxf(mx, tm);
+                        const float alpha = TX_EXP((mx - mn) * c2);
+                        oc[0] *= alpha; oc[1] *= alpha; ls *= alpha;
+                        mx = mn;
+                    } else if (kt == 0) {
+                        mx = tm;
+                    }
+                    const float nm = -mx * c2;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        if (32 * kt + 16 * s < L) {
+                            uint32_t pk[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float p0 = TX_EXP(fmaf(sc[8 * s + 2 * u], c2, nm));
+                                const float p1 = TX_EXP(fmaf(sc[8 * s + 2 * u + 1], c2, nm));
+                                pk[u] = tx_pack2<T>(p0, p1);
+                                ls = tx_dot2<T>(pk[u], ls);
+                            }
+                            const T8 pf = __builtin_bit_cast(T8, (u32x4){pk[0], pk[1], pk[2], pk[3]});
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+                                oc[ct] = mfma32(*reinterpret_cast<const T8*>(vf + (4 * kt + 2 * s) * 1024 + ct * 512), pf, oc[ct]);
+                        }
                 }
             }
-            // ---- one maximum per row (the lane's 8 keys per valid half tile, then the other half of the wave) ----
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    if (32 * kt + 16 * s < L) {
-#pragma unroll
-                        for (int i = 8 * s; i < 8 * s + 8; ++i) mx = fmaxf(mx, sc[kt][i]);
-                    }
-            mx = max_halves(mx);
-            const float nm = -mx * c2;
-            // ---- probabilities, row sum (of the rounded values the second product uses), O^T = V^T P^T ----
-            f32x16 oc[2] = {tx_zero16(), tx_zero16()};
-            float ls = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    if (32 * kt + 16 * s < L) {
-                        uint32_t pk[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const float p0 = TX_EXP(fmaf(sc[kt][8 * s + 2 * u], c2, nm));
-                            const float p1 = TX_EXP(fmaf(sc[kt][8 * s + 2 * u + 1], c2, nm));
-                            pk[u] = tx_pack2<T>(p0, p1);
-                            ls = tx_dot2<T>(pk[u], ls);
-                        }
-                        const T8 pf = __builtin_bit_cast(T8, (u32x4){pk[0], pk[1], pk[2], pk[3]});
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct)
-                            oc[ct] = mfma32(*reinterpret_cast<const T8*>(vf + (4 * kt + 2 * s) * 1024 + ct * 512), pf, oc[ct]);
-                    }
             ls = sum_halves(ls);
             // ---- combine ----
             const int rl = NSEG == 1 ? 0 : sg == 0 ? role0 : sg == 1 ? role1 : 2;
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
                     m_own = mx; l_own = ls;
                 }
             } else {
-                const float side = rl == 1 ? 1.f - cf : cf;
+                const float side = inner ? 1.f : rl == 1 ? 1.f - cf : cf;
                 if (has_own) {
                     const float ms = fmaxf(m_own, mx);
                     const float ao = __builtin_amdgcn_exp2f((m_own - ms) * c2), bo = __builtin_amdgcn_exp2f((mx - ms) * c2);
@@ -314,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
 bool attn_tx_supported(const AidAttnArgs& a) {
     if (a.d != 64 || a.l < 1 || a.l > TXK) return false;
     if (a.dtype != AID_DTYPE_F16 && a.dtype != AID_DTYPE_BF16) return false;
-    if (a.mode != AID_MODE_PLAIN && a.mode != AID_MODE_OUTER) return false;
+    if (a.mode == AID_MODE_INNER && (!a.k2 || !a.vt2)) return false;
     if (a.accumulate) return false;                         // (the IP-Adapter image branch adds into the text result: aid_attn_kernel)
     if (a.ldo % 8 || a.o_fs % 8) return false;              // 16-byte output stores
     return true;
@@ -322,7 +339,7 @@ bool attn_tx_supported(const AidAttnArgs& a) {
 
 template <typename T>
 static hipError_t tx_launch(const AttnTxParams& p, hipStream_t stream) {
-    const bool outer = p.a.mode == AID_MODE_OUTER;
+    const bool outer = p.a.mode != AID_MODE_PLAIN;            // INNER / OUTER: the three-region instantiation
     const size_t smem = (size_t)(outer ? 3 : 1) * TX_REGION;
     const void* fn = outer ? reinterpret_cast<const void*>(&aid_attn_tx_kernel<T, 3>) : reinterpret_cast<const void*>(&aid_attn_tx_kernel<T, 1>);
     static PerDevice<int> attr_set;
@@ -344,12 +361,12 @@ hipError_t attn_tx_launch(const AidAttnArgs& a, hipStream_t stream) {
     p.a = a;
     const int ntiles = (a.s + 31) / 32;
     int tpw = tune(TUNE_ATTN_TX_TILES);                      // 32-row tiles per wave (development knob)
-    if (tpw <= 0) tpw = 4;                                   // measured best of 1 .. 8 on the SDXL launches
+    if (tpw <= 0) tpw = ntiles >= 96 ? 4 : 2;                // measured best of 1 / 2 / 4 / 8 on the SDXL launches (S = 4096 : 4, S = 1024 : 2)
     int tpc = 4 * tpw;
     if (tpc > ntiles) tpc = ntiles;
     p.tiles_per_chunk = tpc;
     p.chunks = (ntiles + tpc - 1) / tpc;
-    const int n_heavy = a.mode == AID_MODE_OUTER ? a.n_frames - a.n_plain : 0;
+    const int n_heavy = a.mode != AID_MODE_PLAIN ? a.n_frames - a.n_plain : 0;
     p.na = (n_heavy > 0 && n_heavy < a.n_frames ? n_heavy : 0) * p.chunks;
     p.c2 = a.q_prescaled ? 1.f : a.softmax_scale * 1.4426950408889634f;
     return a.dtype == AID_DTYPE_F16 ? tx_launch<f16>(p, stream) : tx_launch<bf16>(p, stream);

@@ -280,8 +280,8 @@ def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, extra_rows: 
     ``extra_rows``: allocate that many more (uninitialised) frame rows behind the F projected ones — room for the
     end-point frames' keys / values a rank receives from their owners (dist.EndpointExchange).
     ``padded``: the layout of ``AidAttnArgs.kv_padded`` / ``AidProcessorArgs.kv_cached_lt`` — k [F, Lt, C], V^T [F, C, Lt] with
-    Lt = L rounded up to 64, rows / columns L .. Lt zero: short key streams (text cross-attention) then run on the short-stream
-    ping-pong kernel.  Callers read the first L rows / columns (``k[:, :L]``, ``vt[:, :, :L]``)."""
+    Lt = L rounded up to 64, rows / columns L .. Lt zero (an accepted layout; the kernel it was made for was removed in round 5).
+    Callers read the first L rows / columns (``k[:, :L]``, ``vt[:, :, :L]``)."""
     f, l, cc = e.shape
     c = wk.shape[0]
     if padded:

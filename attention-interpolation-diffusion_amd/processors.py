@@ -318,19 +318,16 @@ def _vkey(t: torch.Tensor):
 
 
 def _kv_padded_layout() -> bool:
-    """The tile-padded layout of the cached text keys / values serves the short-stream ping-pong kernel, which is opt-in
-    (development knob ATTN_V2 = 1, profiles/r04_attn_notes.txt); by default the cache keeps the compact layout."""
-    try:
-        return ops.get_tuning("ATTN_V2") == 1
-    except RuntimeError:
-        return False
+    """The tile-padded layout of the cached text keys / values (``AidProcessorArgs.kv_cached_lt``) served round 4's short-stream
+    kernel, removed in round 5; the cache keeps the compact layout.  (The library still accepts the padded layout.)"""
+    return False
 
 
 def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tensor, padded: bool = False):
     """(k [n_ctx, L, C], vt [n_ctx, C, Lp]) of the distinct contexts ``ctx`` derived from the caller's tensor ``ehs``
     (``idx`` = frame -> context map or None), from the cache or projected now; None where caching does not apply.
     ``padded`` (every mode but INNER, whose interpolated keys are laid out compactly): rows / columns up to the next multiple of
-    64 keys, zero beyond L — the layout the short-stream ping-pong kernel reads (``AidProcessorArgs.kv_cached_lt``)."""
+    64 keys, zero beyond L (``AidProcessorArgs.kv_cached_lt``; an accepted layout that no kernel requires since round 5)."""
     if not TEXT_KV_CACHE or ehs is None or not torch.is_tensor(ehs):
         return None
     ks = (_vkey(ehs), _vkey(wk), _vkey(wv))

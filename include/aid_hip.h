@@ -187,8 +187,8 @@ typedef struct AidAttnArgs {
                                  /* algorithmic count; 0 = unknown (reported equal to the algorithmic count)     */
     int32_t kv_padded;           /* 1: every row of k holds at least round_up(l, 64) key rows (k_fs >= that * ldk) and every row   */
                                  /* of vt at least round_up(l, 64) columns (ldvt >= that); key rows l .. are FINITE, value columns */
-                                 /* l .. are ZERO.  Lets short key streams (text cross-attention, l = 77) run on the ping-pong    */
-                                 /* kernel for short streams (csrc/aid_attn_xs.hip); 0: no such guarantee (ABI v6; was reserved0)  */
+                                 /* l .. are ZERO.  A layout promise the caller may make (ABI v6; was reserved0); no kernel depends */
+                                 /* on it since round 5 (the short-stream kernel it served was removed); 0: no such guarantee      */
 } AidAttnArgs;
 
 int aid_attn_fwd(const AidAttnArgs* args /* host */, void* stream);

@@ -1,10 +1,11 @@
 """GPU: the text-key attention kernel (csrc/aid_attn_tx.hip: d = 64, at most 96 keys per segment resident in LDS, independent waves,
-exact two-pass softmax per segment, OUTER sides combined from the segments' maxima and row sums; opt-in through the development knob
-ATTN_TX = 1 — launch by launch it is 5 - 16 % faster than the default kernel, in the stack 0.1 %: profiles/r05_attn_tx_notes.txt)
-against the fp64 oracle and against the program-order kernel (ATTN_TX = 0) on the same call.  PLAIN calls,
+online softmax over the segment's score tiles, OUTER sides combined from the segments' maxima and row sums — the default for the
+cross-attention calls of the SDXL stack, profiles/r05_attn_tx_notes.txt) against the fp64 oracle and against the program-order kernel
+(ATTN_TX = 0) on the same call.  PLAIN calls,
 fused and pure OUTER calls with PLAIN riders, interior rows with end-point coefficients, shared contexts (kv_map), per-frame / output
 scales, a pre-scaled q, every key count 1 .. 96 (ragged and whole score tiles), ragged query counts, forced large score ranges between
-the segments, the SDXL layer shapes with repetition, and what the kernel hands back to aid_attn_kernel (accumulate, > 96 keys, INNER)."""
+the segments, the SDXL layer shapes with repetition, INNER calls (one interpolated segment), and what the kernel hands back to aid_attn_kernel
+(accumulating calls, > 96 keys, other head dims)."""
 import numpy as np
 import pytest
 import torch
@@ -18,11 +19,6 @@ import aid_amd  # noqa: E402
 from aid_amd import ops  # noqa: E402
 
 DEV = "cuda:0"
-
-
-@pytest.fixture(autouse=True)
-def _tx_on(tuning):
-    tuning("ATTN_TX", 1)
 
 
 DTYPES = [torch.float16, torch.bfloat16]
@@ -155,16 +151,44 @@ def test_every_kind_of_key_count(l):
     assert torch.isfinite(o).all() and rel_l2(to_np64(o), ref) < TOL[dtype] and worst(to_np64(o), ref) < WORST[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "pure"])
+@pytest.mark.parametrize("l,s,riders,h", [(77, 300, 7, 3), (64, 200, 0, 2), (20, 130, 3, 5)], ids=["l77", "l64", "l20"])
+def test_inner_call_with_riders(dtype, fused, l, s, riders, h, tuning):
+    """INNER: ONE interpolated key segment (rows written by aid_lerp_kv; the end-point frame itself for a coefficient of exactly 0 / 1)
+    beside the own keys under one softmax, PLAIN riders in the same launch; every frame against the oracle."""
+    n = 7
+    q, k, v = _inputs(n + riders, n + riders, s, l, h, dtype, seed=3 * l + s + fused)
+    k[0, min(5, l - 1)] = q[2, 7 % s] * 5.0
+    coef = torch.from_numpy(O.beta_coefs(n, 3, 3)).float()
+    coef[1], coef[5] = 0.0, 1.0
+    cd = torch.cat([coef.to(dtype).float(), -torch.ones(riders)])
+    kc, vc = _compact(k, v)
+    args = dict(l=l, mode="inner", fused=fused, coef=cd.to(DEV), begin=0, end=n - 1, n_plain=riders)
+    o = ops.attn_fwd(q.to(DEV), kc, vc, h, **args)
+    assert ops.last_attn_variant() == "aid_attn_tx<d64,inner>"
+    q64, k64, v64 = to_np64(q), to_np64(k), to_np64(v)
+    ref = O.attn_core(q64[:n], k64[:n], v64[:n], h, 64 ** -0.5, "inner", fused, coef.to(dtype).float().numpy())
+    if riders:
+        ref = np.concatenate([ref, O.attn_core(q64[n:], k64[n:], v64[n:], h, 64 ** -0.5, "plain", False, None)])
+    assert torch.isfinite(o).all()
+    for f in range(n + riders):
+        assert rel_l2(to_np64(o[f]), ref[f]) < TOL[dtype], f
+    assert worst(to_np64(o), ref) < WORST[dtype]
+    assert torch.equal(ops.attn_fwd(q.to(DEV), kc, vc, h, **args), o)
+    if riders:                      # a rider inside an INNER launch = the same frame in a PLAIN call, bit for bit
+        op = ops.attn_fwd(q[n:].contiguous().to(DEV), kc[n:].contiguous(), vc[n:].contiguous(), h, l=l, mode="plain")
+        assert torch.equal(o[n:], op)
+    tuning("ATTN_TX", 0)
+    o_old = ops.attn_fwd(q.to(DEV), kc, vc, h, **args)
+    assert "aid_attn_tx" not in ops.last_attn_variant() and rel_l2(to_np64(o), to_np64(o_old)) < TOL[dtype]
+
+
 def test_calls_that_stay_on_the_other_kernels():
     dtype, n, s, h = torch.bfloat16, 3, 64, 2
-    coef = torch.tensor([0.0, 0.4, 1.0]).to(DEV)
     q, k, v = _inputs(n, n, s, 97, h, dtype, seed=1)            # 97 keys: one more than the LDS regions hold
     kc, vc = _compact(k, v)
     ops.attn_fwd(q.to(DEV), kc, vc, h, l=97, mode="plain")
-    assert "aid_attn_tx" not in ops.last_attn_variant()
-    q, k, v = _inputs(n, n, s, 77, h, dtype, seed=2)
-    kc, vc = _compact(k, v)
-    ops.attn_fwd(q.to(DEV), kc, vc, h, l=77, mode="inner", fused=True, coef=coef, begin=0, end=2)
     assert "aid_attn_tx" not in ops.last_attn_variant()
     g = torch.Generator().manual_seed(3)                        # head dim 40 (SD1.5)
     q40, k40, v40 = (torch.randn(n, s, 80, generator=g).to(dtype) for _ in range(3))
@@ -189,14 +213,14 @@ def test_sdxl_cross_attention_shapes_sampled_rows(tuning):
             kw = dict(l=l, mode=mode, kv_map=kv_map.to(DEV))
             if mode == "outer":
                 kw.update(fused=True, coef=cd.to(DEV), begin=0, end=2, n_plain=riders)
-            tuning("ATTN_TX", 1)
+            tuning("ATTN_TX", -1)
             o = ops.attn_fwd(q.to(DEV), kc, vc, h, **kw)
             assert "aid_attn_tx" in ops.last_attn_variant() and torch.isfinite(o).all()
             tuning("ATTN_TX", 0)
             o_old = ops.attn_fwd(q.to(DEV), kc, vc, h, **kw)
             assert "aid_attn_tx" not in ops.last_attn_variant()
             assert rel_l2(to_np64(o), to_np64(o_old)) < TOL[dtype], (s, mode)
-            tuning("ATTN_TX", 1)
+            tuning("ATTN_TX", -1)
             rows = torch.tensor([0, 31, 32, 255, 256, 700, s - 1])
             q64 = to_np64(q[:, rows])
             k64, v64 = to_np64(k)[kv_map.long().numpy()], to_np64(v)[kv_map.long().numpy()]
@@ -233,3 +257,22 @@ def test_processor_path(kind):
     y = proc(attn, x, encoder_hidden_states=ctx)
     assert "aid_attn_tx" in ops.last_attn_variant(), ops.last_attn_variant()
     assert torch.equal(y, proc(attn, x, encoder_hidden_states=ctx)) and rel_l2(to_np64(y), ref) < TOL[dtype]
+
+
+def test_padded_text_cache_layout_is_still_accepted():
+    """ops.project_kv(padded=True) / AidAttnArgs.kv_padded (ABI v6): rows / columns up to a multiple of 64 keys, zero beyond L — the
+    layout round 4's short-stream kernel needed.  That kernel is gone; the layout stays a valid way to hand keys / values over."""
+    dtype, f, l, cc, c = torch.bfloat16, 3, 77, 256, 192
+    g = torch.Generator().manual_seed(1)
+    e = torch.randn(f, l, cc, generator=g).to(dtype).to(DEV)
+    wk = (torch.randn(c, cc, generator=g) / 16).to(dtype).to(DEV)
+    wv = (torch.randn(c, cc, generator=g) / 16).to(dtype).to(DEV)
+    k, vt = ops.project_kv(e, wk, wv)
+    kp, vtp = ops.project_kv(e, wk, wv, padded=True)
+    assert tuple(kp.shape) == (f, 128, c) and tuple(vtp.shape) == (f, c, 128)
+    assert torch.equal(kp[:, :l], k) and torch.equal(vtp[:, :, :l], vt[:, :, :l])
+    assert not kp[:, l:].any() and not vtp[:, :, l:].any()
+    q = torch.randn(f, 200, c, generator=g).to(dtype).to(DEV)
+    o_pad = ops.attn_fwd(q, kp, vtp, 3, l=l, mode="plain", kv_padded=True)
+    assert ops.last_attn_variant() == "aid_attn_tx<d64,plain>"
+    assert torch.equal(o_pad, ops.attn_fwd(q, k, vt, 3, l=l, mode="plain"))

@@ -184,6 +184,7 @@ def test_attention_every_ragged_key_count(dtype, d, resident, tuning):
     resident kernel: hipcc left too few wait states between the last MFMA of a score block and the first VALU read of it
     on the taken path (keys 22 / 30 of the tile lost their last k-step) — the tile is straight-line now."""
     tuning("ATTN_RES", int(resident))
+    tuning("ATTN_TX", 0)            # (d = 64 PLAIN / OUTER calls of <= 96 keys default to the text-key kernel: tests/test_hip_attn_tx.py)
     n, s, h = 3, 48, 2
     coef = _coef(n)
     for l in (1, 7, 8, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 77, 80, 88, 95, 96, 97, 120, 128, 160):

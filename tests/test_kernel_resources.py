@@ -37,7 +37,7 @@ def _attn(tab):
 
 
 def test_no_kernel_spills_or_uses_scratch():
-    for obj in ("aid_attn", "aid_attn_pp", "aid_gemm", "aid_gemm_rs", "aid_f32", "aid_norm"):
+    for obj in ("aid_attn", "aid_attn_pp", "aid_attn_tx", "aid_gemm", "aid_gemm_rs", "aid_f32", "aid_norm"):
         for sym, r in _table(obj).items():
             assert r["scratch"] == 0 and r["spill"] == 0, (obj, sym, r)
 
@@ -50,10 +50,10 @@ def test_sgpr_spills_are_bounded():
     segments not being walked); the ping-pong kernel keeps two item records (the one it computes, the one it planned) and spills
     38 (PLAIN) / 57 - 115 (INNER, OUTER) of them in its per-mode instantiations of round 4 (82 in the one-kernel-for-all-modes
     version of round 3) — all in the prologue / item planning / item boundary, at most three v_readlane in a PLAIN V slot (counted
-    per barrier interval in the ISA; an earlier version with spills in the loop was 9 % slower); the short-stream kernel plans its
-    whole item queue up front into VGPR lanes and spills 17 / 26.
+    per barrier interval in the ISA; an earlier version with spills in the loop was 9 % slower); the text-key kernel (aid_attn_tx) keeps the whole
+    argument record live across its tile loop and spills 20 (PLAIN) / 63 (INNER / OUTER: three segments' roles and sources).
     VERDICT r2 weak #10."""
-    for obj, bound in (("aid_gemm", 0), ("aid_gemm_rs", 0), ("aid_norm", 0), ("aid_attn_pp", 120), ("aid_attn_xs", 32), ("aid_attn", 32)):
+    for obj, bound in (("aid_gemm", 0), ("aid_gemm_rs", 0), ("aid_norm", 0), ("aid_attn_pp", 120), ("aid_attn_tx", 72), ("aid_attn", 32)):
         for sym, r in _table(obj).items():
             assert r["sgpr_spill"] <= bound, (obj, sym, r)
 
@@ -89,12 +89,23 @@ def test_pingpong_attention_keeps_two_waves_per_simd():
     state of a two-sided frame and the -m block in them (round 4, one instantiation per mode: PLAIN / INNER 215 - 220, OUTER 246 - 250;
     the park / swap code inside the unrolled tile loop had it at 256 + 14 spills, a select between two by-value argument fields
     had put 416 B per lane into scratch, and staging OUTER's output through LDS needed 256 + 8 spills — it stores directly).
-    The short-stream kernel (ATTN_V2 = 1) has the same premise: 204 (PLAIN) / 243 (OUTER)."""
-    syms = {**_table("aid_attn_pp"), **_table("aid_attn_xs")}
-    assert sum("aid_attn_pp_kernel" in s for s in syms) == 6 and sum("aid_attn_xs_kernel" in s for s in syms) == 4
+    """
+    syms = _table("aid_attn_pp")
+    assert sum("aid_attn_pp_kernel" in s for s in syms) == 6
     for sym, r in syms.items():
-        if "aid_attn_pp_kernel" in sym or "aid_attn_xs_kernel" in sym:
+        if "aid_attn_pp_kernel" in sym:
             assert r["vgpr"] + r["agpr"] <= 256 and r["occ"] >= 2 and r["scratch"] == 0 and r["spill"] == 0, (sym, r)
+
+
+def test_text_key_attention_keeps_the_waves_per_simd_its_latency_hiding_needs():
+    """aid_attn_tx hides the latency of its Q rows behind OTHER waves: the PLAIN instantiation has to stay at four waves per SIMD
+    (<= 128 VGPRs: 16 score registers + two 16-register output blocks + two Q tiles), the OUTER one at two with three output blocks
+    and no scratch (profiles/r05_attn_tx_notes.txt)."""
+    syms = _table("aid_attn_tx")
+    assert len(syms) == 4
+    for sym, r in syms.items():
+        plain = "Li1EEE" in sym
+        assert r["occ"] >= (4 if plain else 2) and r["scratch"] == 0 and r["spill"] == 0, (sym, r)
 
 
 def test_gemm_engines_fit_their_workgroups_per_cu():

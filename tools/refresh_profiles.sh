@@ -18,8 +18,7 @@ cd $GRAFT_REPO_ROOT
 for w in sdxl sd15; do python tools/stack_breakdown.py $w > $R/breakdown_$w.txt 2>/dev/null; done
 python tools/kbench_proj.py > $R/kbench_proj.txt 2>/dev/null
 python tools/kbench_attn_ab.py "ATTN_V2=-1" "ATTN_V2=0" --rounds 5 --iters 6 --shapes sdxl --inner > $R/kbench_attn.txt 2>/dev/null
-python tools/dev/xs_ab.py > $R/xs_ab.txt 2>/dev/null
-python tools/kbench_attn_ab.py "ATTN_TX=0" "ATTN_TX=1" --rounds 5 --iters 6 --shapes sdxl --only x77 > $R/kbench_attn_tx.txt 2>/dev/null
+python tools/kbench_attn_ab.py "ATTN_TX=0" "ATTN_TX=-1" --rounds 5 --iters 6 --shapes sdxl --only x77 > $R/kbench_attn_tx.txt 2>/dev/null
 python tools/gemm_ab.py "GEMM_TRI=0,GEMM_PP=0" "GEMM_TRI=0,GEMM_PP=1" "GEMM_TRI=-1,GEMM_PP=1" --rounds 5 --iters 10 --torch > $R/gemm_ab.txt 2>/dev/null
 python tools/gemm_ab.py "GEMM_RS=0" "GEMM_RS=-1" "GEMM_RS=1" --short --rounds 5 --iters 10 > $R/gemm_rs_ab.txt 2>/dev/null
 for u in mfma_cadence store_bw valu_rate barrier_cost wave_simd head_stride_copy; do
