@@ -63,6 +63,7 @@ try:
     got2 = adist.gather_owned(y_ex, own)
     torch.cuda.synchronize()
     assert got2.shape == want.shape and rel(got2, want) < 8e-3, ("endpoint exchange", rel(got2, want))
-    print(f"OK {rank}", flush=True)
+    sys.stdout.write(f"OK {rank}\n")
+    sys.stdout.flush()
 finally:
     dist.destroy_process_group()
