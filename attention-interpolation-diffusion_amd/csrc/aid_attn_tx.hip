@@ -84,6 +84,12 @@ __device__ __forceinline__ float tx_dot2<f16>(uint32_t w, float acc) {
 #define TX_EXP(x) __builtin_amdgcn_exp2f(x)
 #endif
 
+#if defined(AID_TX_ABL) && AID_TX_ABL == 4              // development: shader-clock stamps of one wave (tools/dev/tx_timeline.py)
+#define TX_STAMP(i) do { if (tx_trace) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tx_ts[tx_n++] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define TX_STAMP(i) do { } while (0)
+#endif
+
 // NSEG = LDS regions: 1 for PLAIN launches, 3 for OUTER launches (whose frames run one to three segments each).
 template <typename T, int NSEG>
 __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams p) {
@@ -139,6 +145,12 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
     };
     T8 qf[4];
     int t = t0 + wave;
+#if defined(AID_TX_ABL) && AID_TX_ABL == 4
+    const bool tx_trace = blockIdx.x == gridDim.x / 2 && wave == 0;
+    uint64_t tx_ts[40];
+    int tx_n = 0;
+    TX_STAMP(0);                                        // kernel entry
+#endif
     if (t < t_end) load_q(qf, t);                       // in flight across the fill
 
     // ---- fill: every segment of this (frame, head), once per workgroup ------------------------------------------------------------
@@ -195,10 +207,12 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
     const unsigned char* vfrag0 = tx_smem + TX_KBYTES + (h * 64 + m) * 16;         // + region, + (4 kt + 2 s) * 1024 + ct * 512
     const int lim = Lk - 4 * h;                                      // register i of tile kt is a valid key iff 32 kt + 8 (i / 4) + i % 4 < lim
 
+    TX_STAMP(1);                                        // fill done, first Q landed
     for (; t < t_end; t += 4) {
         T8 qn[4];
         const bool more = t + 4 < t_end;
         if (more) load_q(qn, t + 4);
+        TX_STAMP(2);                                    // tile start (next Q requested)
 
         int L = Lk;
         asm volatile("" : "+s"(L));        // the per-half-tile decisions are re-derived per tile (scalar compares) instead of living in spilled SGPR pairs
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
                 }
             }
             ls = sum_halves(ls);
+            TX_STAMP(3);                                // segment done (scores, softmax, second product)
             // ---- combine ----
             const int rl = NSEG == 1 ? 0 : sg == 0 ? role0 : sg == 1 ? role1 : 2;
             if (rl == 0) {
@@ -310,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
         // ORDER MATTERS (loads and stores share vmcnt on gfx950 and the compiler waits for both at once): the next tile's Q — requested
         // before this tile's arithmetic — is waited for HERE, before this tile's stores are issued, so that wait covers loads that had
         // the whole tile to land and stores that are a whole tile old; the stores below then have the next tile to complete.
+        TX_STAMP(4);                                    // output words ready
         if (more) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -317,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
                 asm volatile("" : "+v"(qf[j]));
             }
         }
+        TX_STAMP(5);                                    // next Q landed (and the previous tile's stores)
         {
             const int row = 32 * t + m;
             T* dst = Og + (int64_t)row * a.ldo;
@@ -325,7 +342,18 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
                 for (int w = 0; w < 4; ++w) *reinterpret_cast<u32x4*>(dst + 16 * w) = ow[w];
             }
         }
+        TX_STAMP(6);                                    // stores issued
     }
+#if defined(AID_TX_ABL) && AID_TX_ABL == 4
+    if (tx_trace) {                                     // (overwrites the head of `out`: development only)
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) {
+            uint64_t* dbg = reinterpret_cast<uint64_t*>(a.out);
+            dbg[0] = (uint64_t)tx_n;
+            for (int i = 0; i < tx_n && i < 40; ++i) dbg[1 + i] = tx_ts[i];
+        }
+    }
+#endif
 }
 
 bool attn_tx_supported(const AidAttnArgs& a) {
@@ -361,7 +389,7 @@ hipError_t attn_tx_launch(const AidAttnArgs& a, hipStream_t stream) {
     p.a = a;
     const int ntiles = (a.s + 31) / 32;
     int tpw = tune(TUNE_ATTN_TX_TILES);                      // 32-row tiles per wave (development knob)
-    if (tpw <= 0) tpw = ntiles >= 96 ? 4 : 2;                // measured best of 1 / 2 / 4 / 8 on the SDXL launches (S = 4096 : 4, S = 1024 : 2)
+    if (tpw <= 0) tpw = ntiles >= 96 ? 5 : 3;                // measured best of 1 ... 16 on the SDXL launches (S = 4096 : 5, S = 1024 : 3; flat within 3 % from 2 to 5)
     int tpc = 4 * tpw;
     if (tpc > ntiles) tpc = ntiles;
     p.tiles_per_chunk = tpc;
