@@ -45,9 +45,9 @@ def bench_name(sym):
         return f"aid_attn<{dt},d{m.group(1)},{MODES[m.group(2)]},nw{m.group(3)}{sfx}>"
     if "aid_attn_pp_kernel" in sym:                     # one device symbol behind aid_attn_pp<dt,d64> and aid_attn_pp<dt,d64,outer>
         return f"aid_attn_pp<{dt},d64>"
-    m = re.search(r"aid_attn_tx_kernelIDF16b?_?Li(\d)", sym)
-    if m:
-        return f"aid_attn_tx<{dt},d64,{'plain' if m.group(1) == '1' else 'outer'}>"
+    if "aid_attn_tx_kernel" in sym:          # (rocprofv3 prints the one-region instantiation through a broken demangling: no "Li1")
+        m = re.search(r"aid_attn_tx_kernelIDF16b?_?Li(\d)", sym)
+        return f"aid_attn_tx<{dt},d64,{'outer' if m and m.group(1) == '3' else 'plain'}>"
     for k in ("aid_gemm_rs_kernel", "aid_gemm_nt_ppx_kernel", "aid_gemm_nt_pp_kernel", "aid_gemm_nt_pipe_kernel", "aid_gemm_nt_kernel", "aid_lerp_kv_kernel",
               "aid_layernorm_kernel", "aid_ln_stats_kernel"):
         if k in sym:
