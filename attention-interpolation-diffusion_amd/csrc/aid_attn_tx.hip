@@ -12,7 +12,7 @@
 //   * a wave owns 32 query rows at a time and is independent of the other waves from then on: Q fragments straight from global
 //     memory (the next tile's are requested before the current tile is computed and waited for BEFORE the current tile's stores are
 //     issued: loads and stores share vmcnt), one 32-key score tile at a time with an online softmax over the segment's <= 3 tiles
-//     (16 score registers: 120 VGPRs = four waves per SIMD for PLAIN launches, 218 and no scratch for OUTER ones), 16-key halves past
+//     (16 score registers: 111 VGPRs = four waves per SIMD for PLAIN launches, 210 and no scratch for INNER / OUTER ones), 16-key halves past
 //     L skipped;
 //   * the segments of a fused OUTER frame are combined at the end from their maxima and row sums:
 //         out = (1 - c) [a1 O_own + b1 O_beg] / (a1 l_own + b1 l_beg) + c [a2 O_own + b2 O_end] / (a2 l_own + b2 l_end),
@@ -208,12 +208,8 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
     const int lim = Lk - 4 * h;                                      // register i of tile kt is a valid key iff 32 kt + 8 (i / 4) + i % 4 < lim
 
     TX_STAMP(1);                                        // fill done, first Q landed
-    for (; t < t_end; t += 4) {
-        T8 qn[4];
-        const bool more = t + 4 < t_end;
-        if (more) load_q(qn, t + 4);
-        TX_STAMP(2);                                    // tile start (next Q requested)
-
+    // one 32-row tile: scores, softmax, second product of every segment, the combination, the packed output words
+    auto compute = [&](const T8 (&qf)[4], u32x4 (&ow)[4]) {
         int L = Lk;
         asm volatile("" : "+s"(L));        // the per-half-tile decisions are re-derived per tile (scalar compares) instead of living in spilled SGPR pairs
         f32x16 o_own[2], res[2] = {tx_zero16(), tx_zero16()};
@@ -311,7 +307,6 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
         }
 
         // ---- output words: lane (row m, half h) holds channels 32 ct + 8 g + 4 h + {0..3}; after the swaps 32 ct + 16 u + 8 h + {0..7} ----
-        u32x4 ow[4];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -322,6 +317,22 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
                 const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
                 ow[2 * ct + u] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
             }
+    };
+    auto store_rows = [&](const u32x4 (&ow)[4], int tt) {
+        const int row = 32 * tt + m;
+        T* dst = Og + (int64_t)row * a.ldo;
+        if (row < a.s) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) *reinterpret_cast<u32x4*>(dst + 16 * w) = ow[w];
+        }
+    };
+    for (; t < t_end; t += 4) {
+        T8 qn[4];
+        const bool more = t + 4 < t_end;
+        if (more) load_q(qn, t + 4);
+        TX_STAMP(2);                                    // tile start (next Q requested)
+        u32x4 ow[4];
+        compute(qf, ow);
         // ORDER MATTERS (loads and stores share vmcnt on gfx950 and the compiler waits for both at once): the next tile's Q — requested
         // before this tile's arithmetic — is waited for HERE, before this tile's stores are issued, so that wait covers loads that had
         // the whole tile to land and stores that are a whole tile old; the stores below then have the next tile to complete.
@@ -334,14 +345,7 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
             }
         }
         TX_STAMP(5);                                    // next Q landed (and the previous tile's stores)
-        {
-            const int row = 32 * t + m;
-            T* dst = Og + (int64_t)row * a.ldo;
-            if (row < a.s) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) *reinterpret_cast<u32x4*>(dst + 16 * w) = ow[w];
-            }
-        }
+        store_rows(ow, t);
         TX_STAMP(6);                                    // stores issued
     }
 #if defined(AID_TX_ABL) && AID_TX_ABL == 4
