@@ -34,6 +34,10 @@ PASSES = [
 ]
 
 
+WORKLOAD_DTYPE = {"sdxl": "bf16", "seq16": "bf16", "ip": "bf16", "sd15": "f16"}
+CURRENT = [None]                       # workload being collected (bench_name needs it for one broken demangling)
+
+
 def bench_name(sym):
     """kernel symbol -> the name bench.py's roofline object uses"""
     dt = "bf16" if "IDF16b" in sym else "f16"
@@ -45,8 +49,10 @@ def bench_name(sym):
         return f"aid_attn<{dt},d{m.group(1)},{MODES[m.group(2)]},nw{m.group(3)}{sfx}>"
     if "aid_attn_pp_kernel" in sym:                     # one device symbol behind aid_attn_pp<dt,d64> and aid_attn_pp<dt,d64,outer>
         return f"aid_attn_pp<{dt},d64>"
-    if "aid_attn_tx_kernel" in sym:          # (rocprofv3 prints the one-region instantiation through a broken demangling: no "Li1")
-        m = re.search(r"aid_attn_tx_kernelIDF16b?_?Li(\d)", sym)
+    if "aid_attn_tx_kernel" in sym:          # (rocprofv3 prints the one-region instantiation through a broken demangling: neither the
+        m = re.search(r"aid_attn_tx_kernelIDF16b?_?Li(\d)", sym)      # dtype nor "Li1" survive; the workloads run it in one dtype each)
+        if not m:
+            dt = WORKLOAD_DTYPE.get(CURRENT[0], dt)
         return f"aid_attn_tx<{dt},d64,{'outer' if m and m.group(1) == '3' else 'plain'}>"
     for k in ("aid_gemm_rs_kernel", "aid_gemm_nt_ppx_kernel", "aid_gemm_nt_pp_kernel", "aid_gemm_nt_pipe_kernel", "aid_gemm_nt_kernel", "aid_lerp_kv_kernel",
               "aid_layernorm_kernel", "aid_ln_stats_kernel"):
@@ -57,6 +63,7 @@ def bench_name(sym):
 
 
 def collect(workload, counters):
+    CURRENT[0] = workload
     out = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "2", "--no-graph",
