@@ -1767,7 +1767,11 @@ static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char**
         pl = plan_pp(g, ncu, nk);                   // last: leaves g.tile_start in 256 x 256 units for launch_pp
         const double r128 = 0.5 * (double)((2 * t128 + 2 * ncu - 1) / (2 * ncu));       // rounds of 2 CUs-fulls, in halves
         const double cost_ls = 3.0 + r128 * (4.1 + 1.09 * nk);
-        const double cost_pp = 5.0 + pl.rounds * (6.0 + 1.62 * nk);
+        // (a single round that leaves CUs idle runs its tiles faster — less contention for L2 / HBM, a higher clock: measured 35.5 us at
+        //  160 of 256 tiles, 41.3 at 240, 43.4 modelled for a full round, K = 1280; profiles/r05_gemm_shards_ab.txt)
+        const int pp_tiles = pl.n_small ? 0 : pl.tiles;
+        const double occ = (pp_tiles > 0 && pp_tiles <= ncu) ? (double)pp_tiles / ncu : 1.0;
+        const double cost_pp = 5.0 + pl.rounds * (6.0 + 1.62 * nk) * (0.65 + 0.35 * occ);
         pp = cost_pp < 0.95 * cost_ls;
         if (force == 31) pp = true;
     }

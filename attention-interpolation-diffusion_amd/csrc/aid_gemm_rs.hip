@@ -442,7 +442,16 @@ bool gemm_rs_supported(const GemmGroup& g, int ncu, bool ignore_size) {
     int slices = 0;
     for (int i = 0; i < g.n_problems; ++i) slices += g.p[i].n / 32;
     const int rows_per_cu = (k == 320 && slices < 20) ? 192 : 64;
-    return ignore_size || p0.m >= rows_per_cu * ncu;
+    if (ignore_size) return true;
+    if (p0.m < rows_per_cu * ncu) return false;
+    // more row tiles than workgroup slots: whole rounds only.  A 9-frame sequence shard (18 frames batched, 73728 rows at C = 640) is 288
+    // tiles on 256 slots = 0.56 of two rounds: 625 TF/s here against 930 at 512 tiles and ~770 on the tile engines
+    const int tiles = p0.m / tm, slots = (k == 640 ? 1 : 2) * ncu;
+    if (tiles > slots) {
+        const int rounds = (tiles + slots - 1) / slots;
+        if ((double)tiles < 0.8 * (double)rounds * slots) return false;
+    }
+    return true;
 }
 
 hipError_t gemm_rs_launch(const GemmGroup& g, int dtype, int ncu, hipStream_t stream) {

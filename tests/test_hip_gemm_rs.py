@@ -69,6 +69,25 @@ def test_single_projection_bias_scale_residual(dtype, m, n, k, tuning):
     assert ops.last_gemm_variant().startswith("rowstat") == (m >= (49152 if k == 320 else 16384)), ops.last_gemm_variant()
 
 
+def test_default_rule_wants_whole_rounds_of_row_tiles(tuning):
+    """More row tiles than workgroup slots: the engine is chosen only when the rounds are >= 80 % full — a 9-frame sequence shard (18
+    batched frames x 4096 rows = 288 tiles of 256 rows on 256 CUs = 0.56 of two rounds) stays on the tile engines (625 TF/s on this
+    engine against ~770), 32 frames (512 tiles: two whole rounds) take it; GEMM_RS = 1 still forces it.  Same values either way."""
+    dtype, k = torch.bfloat16, 640
+    for m, want in ((18 * 4096, False), (32 * 4096, True)):
+        g, a, (w,) = _operands(m, k, k, dtype, m)
+        y = torch.empty(m, k, dtype=dtype, device=DEV)
+        tuning("GEMM_RS", -1)
+        ops.gemm_nt([dict(a=a, b=w, c=y, m=m, n=k, k=k, lda=k, ldb=k, ldc=k)])
+        assert ops.last_gemm_variant().startswith("rowstat") == want, (m, ops.last_gemm_variant())
+        if not want:
+            tuning("GEMM_RS", 1)
+            y1 = torch.empty_like(y)
+            ops.gemm_nt([dict(a=a, b=w, c=y1, m=m, n=k, k=k, lda=k, ldb=k, ldc=k)])
+            assert ops.last_gemm_variant().startswith("rowstat")
+            _same(y1, y, dtype)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
 @pytest.mark.parametrize("frames,keys,c", [(2, 1024, 640),      # K = 640, slice range split six ways
                                            (3, 256, 320),       # K = 320

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-process interleaved A/B of GEMM engine variants (aid_set_tuning) at the projection shapes of the SDXL stack.
-usage: python tools/gemm_ab.py "GEMM_PP=0" "GEMM_PP=1" "GEMM_PP=2" [--rounds 5] [--iters 10] [--torch] [--ksweep]
+usage: python tools/gemm_ab.py "GEMM_PP=0" "GEMM_PP=1" "GEMM_PP=2" [--rounds 5] [--iters 10] [--torch] [--ksweep] [--short] [--shards] [--sd15]
 Every variant string is a comma-separated list of NAME=value knobs.  Prints median us and TF/s per shape and variant."""
 import os
 import statistics
@@ -34,6 +34,9 @@ if "--short" in sys.argv:        # the short-K levels (row-stationary engine, GE
               ("sdxl L1 qkv 3x(28672,640,640)", [(28672, 640, 640)] * 3), ("sdxl L1 out (28672,640,640)", [(28672, 640, 640)]),
               ("sd15 L0 qkv 3x(57344,320,320)", [(57344, 320, 320)] * 3), ("sd15 L0 out (57344,320,320)", [(57344, 320, 320)]),
               ("sd15 L0 qkv 3x(28672,320,320)", [(28672, 320, 320)] * 3), ("sd15 L0 out (28672,320,320)", [(28672, 320, 320)])]
+if "--shards" in sys.argv:       # the C = 1280 projections at the local batches of a sharded 16-frame sequence (2 x 4 / 6 / 9 frames x 1024 rows)
+    SHAPES = [(f"sdxl L2 {nm} {f}f ({m},1280,1280)", [(m, 1280, 1280)] * c) for f in (4, 6, 9) for m in (2 * f * 1024,)
+              for nm, c in (("qkv 3x", 3), ("out", 1))]
 if "--sd15" in sys.argv:
     SHAPES = [("sd15 L0 qkv 3x(57344,320,320)", [(57344, 320, 320)] * 3), ("sd15 L0 out", [(57344, 320, 320)]),
               ("sd15 L1 qkv 3x(14336,640,640)", [(14336, 640, 640)] * 3), ("sd15 L1 out", [(14336, 640, 640)]),
