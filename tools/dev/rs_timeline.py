@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timeline of the row-stationary GEMM kernel (development build libaid_rsvar.so, GEMM_PP=3 = VAR 9): shader-clock stamps of
-workgroup 0, waves 0 (early) and 4 (late), per slice step.  usage: AID_LIB_PATH=tools/dev/libaid_rsvar.so python tools/dev/rs_timeline.py"""
+workgroup 0, waves 0 (early) and 4 (late), per slice step.  usage: make -C tools/dev libaid_rsvar.so && AID_LIB_PATH=tools/dev/libaid_rsvar.so python tools/dev/rs_timeline.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

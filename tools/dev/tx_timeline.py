@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase timeline of the text-key attention kernel (development build with -DAID_TX_ABL=4): shader-clock stamps of wave 0 of the middle
 workgroup — kernel entry, fill done, then per 32-row tile: start (next Q requested), every segment done, output words ready, next Q
-landed, stores issued.  usage: AID_LIB_PATH=<dev lib> python tools/dev/tx_timeline.py [plain|outer] [S] [tiles per wave]"""
+landed, stores issued.  usage: make -C tools/dev libaid_tx_abl4.so && AID_LIB_PATH=tools/dev/libaid_tx_abl4.so python tools/dev/tx_timeline.py [plain|outer] [S] [tiles per wave]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
