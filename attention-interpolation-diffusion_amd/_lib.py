@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AID_LIB_PATH") or os.path.join(PKG_DIR, "libaid_hip.so")   # override: development A/B builds
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
-AID_ABI_VERSION = 7
+AID_ABI_VERSION = 8
 DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
 MODE_PLAIN, MODE_INNER, MODE_OUTER = 0, 1, 2
 GEMM_MAX_PROBLEMS = 6
@@ -56,7 +56,8 @@ class AidAttnArgs(C.Structure):
         ("accumulate", C.c_int32), ("dtype", C.c_int32),
         ("softmax_scale", C.c_float), ("out_scale", C.c_float),
         ("n_plain", C.c_int32), ("q_prescaled", C.c_int32),
-        ("seg_executed", C.c_int32), ("kv_padded", C.c_int32),
+        ("seg_executed", C.c_int32), ("reserved0", C.c_int32),
+        ("bias", C.c_void_p), ("bias_fs", C.c_int64), ("bias_hs", C.c_int32), ("bias_rs", C.c_int32),
     ]
 
 
@@ -74,10 +75,11 @@ class AidProcessorArgs(C.Structure):
         ("ip", C.c_void_p), ("wk_ip", C.c_void_p), ("wv_ip", C.c_void_p), ("ip_map", C.c_void_p),
         ("ip_frame_scale", C.c_void_p), ("ip_stride", C.c_int64),
         ("n_ip", C.c_int32), ("t_ip", C.c_int32), ("ip_mode", C.c_int32), ("ip_scale", C.c_float),
-        ("ip_begin", C.c_int32), ("ip_end", C.c_int32), ("seg_executed", C.c_int32), ("kv_cached_lt", C.c_int32),
+        ("ip_begin", C.c_int32), ("ip_end", C.c_int32), ("seg_executed", C.c_int32), ("reserved2", C.c_int32),
         ("ln_wq", C.c_void_p), ("ln_wk", C.c_void_p), ("ln_wv", C.c_void_p), ("ln_const", C.c_void_p),
         ("k_cached", C.c_void_p), ("vt_cached", C.c_void_p),
         ("cu_share", C.c_int32), ("reserved1", C.c_int32),
+        ("attn_bias", C.c_void_p), ("attn_bias_fs", C.c_int64), ("attn_bias_hs", C.c_int32), ("attn_bias_rs", C.c_int32),
     ]
 
 

@@ -50,9 +50,19 @@ class AttnShim(nn.Module):
 
     # -- the helpers the reference processors call ---------------------------
     def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
+        """diffusers' ``Attention.prepare_attention_mask`` (third-party, restated from diffusers 0.27 - 0.31; not in SURVEY.md App. A,
+        which only needed the ``None`` case): an additive mask ``[B, 1 | S, L]`` is padded when its length differs from the key
+        sequence's — by ``target_length`` zeros, diffusers' own quirk — and repeated per head to ``[B * H, 1 | S, L]``."""
         if attention_mask is None:
             return None
-        raise NotImplementedError("UNet attention never passes a mask (SURVEY.md §3.2)")
+        if attention_mask.shape[-1] != target_length:
+            attention_mask = torch.nn.functional.pad(attention_mask, (0, target_length), value=0.0)
+        if out_dim == 3:
+            if attention_mask.shape[0] < batch_size * self.heads:
+                attention_mask = attention_mask.repeat_interleave(self.heads, dim=0)
+        elif out_dim == 4:
+            attention_mask = attention_mask.unsqueeze(1).repeat_interleave(self.heads, dim=1)
+        return attention_mask
 
     def head_to_batch_dim(self, tensor: torch.Tensor, out_dim: int = 3) -> torch.Tensor:
         h = self.heads

@@ -32,11 +32,14 @@ struct ProfRec {
 std::atomic<bool> g_prof_on{false};
 std::mutex g_prof_mu;                      // guards g_prof: launches of several host threads may be profiled at once
 std::vector<ProfRec> g_prof;
+unsigned g_prof_gen = 0;                   // bumped by aid_profile_begin (under g_prof_mu): a ProfScope that straddles a restart of the
+                                           // recorder must not write into the NEW list's record that happens to sit at its index
 
 struct ProfScope {          // records an event pair around one launch when profiling is on
     hipStream_t stream;
     bool on;
     size_t idx = 0;         // this launch's record (other threads may append while the launch is being issued)
+    unsigned gen = 0;       // recorder generation the record belongs to
     ProfScope(hipStream_t s, const char* name, double flops, double bytes, double flops_exec = -1.0)
         : stream(s), on(g_prof_on.load(std::memory_order_relaxed)) {
         if (!on) return;
@@ -50,19 +53,20 @@ struct ProfScope {          // records an event pair around one launch when prof
         (void)hipEventRecord(r.t0, stream);
         std::lock_guard<std::mutex> lk(g_prof_mu);
         idx = g_prof.size();
+        gen = g_prof_gen;
         g_prof.push_back(r);
     }
     void rename(const char* name) {      // the kernel symbol is known only after the launcher picked an engine
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (idx < g_prof.size()) snprintf(g_prof[idx].name, sizeof(g_prof[idx].name), "%s", name);
+        if (gen == g_prof_gen && idx < g_prof.size()) snprintf(g_prof[idx].name, sizeof(g_prof[idx].name), "%s", name);
     }
     ~ProfScope() {
         if (!on) return;
         hipEvent_t t1 = nullptr;
         {
             std::lock_guard<std::mutex> lk(g_prof_mu);
-            if (idx < g_prof.size()) t1 = g_prof[idx].t1;
+            if (gen == g_prof_gen && idx < g_prof.size()) t1 = g_prof[idx].t1;
         }
         if (t1) (void)hipEventRecord(t1, stream);
     }
@@ -184,7 +188,8 @@ int check_processor(const AidProcessorArgs& a) {
     }
     if ((a.k_cached != nullptr) != (a.vt_cached != nullptr)) return AID_ERR_ARG;
     if (a.k_cached && (!a.ctx || !aligned16(a.k_cached) || !aligned16(a.vt_cached))) return AID_ERR_ARG;
-    if (a.kv_cached_lt != 0 && (!a.k_cached || a.mode == AID_MODE_INNER || a.kv_cached_lt % 64 || a.kv_cached_lt < a.l)) return AID_ERR_ARG;
+    if (a.attn_bias && ((a.fused && a.mode != AID_MODE_PLAIN) || a.ip || a.attn_bias_fs < 0 || a.attn_bias_hs < 0 || a.attn_bias_rs < 0))
+        return AID_ERR_ARG;                            // the mask covers one key segment (aid_hip.h); the image branch has no mask to take
     if (!(a.ln_eps >= 0.f) || a.cu_share < 0 || a.cu_share > 8) return AID_ERR_ARG;
     if (a.ln_eps > 0.f) {
         if (!aid::layernorm_width_supported(a.c)) return AID_ERR_SHAPE;
@@ -234,7 +239,7 @@ const char* aid_strerror(int code) {
     switch (code) {
         case AID_OK: return "ok";
         case AID_ERR_ARG: return "invalid argument (NULL pointer, negative size or inconsistent field)";
-        case AID_ERR_DTYPE: return "unsupported dtype (AID_DTYPE_F16 / _BF16 / _F32; the LayerNorm entry points and fusion options are 16-bit only)";
+        case AID_ERR_DTYPE: return "unsupported dtype (AID_DTYPE_F16 / _BF16 / _F32; the LayerNorm entry points and the ln_* options of aid_processor_fwd are 16-bit only)";
         case AID_ERR_SHAPE: return "unsupported shape or alignment (head dim must be 40/64/80/160; see aid_hip.h)";
         case AID_ERR_WORKSPACE: return "workspace too small or misaligned";
         case AID_ERR_LAUNCH: return g_err[0] ? g_err : "kernel launch failed";
@@ -271,6 +276,7 @@ int aid_profile_begin(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
     g_prof.clear();
+    ++g_prof_gen;
     g_prof_on.store(true);
     return AID_OK;
 }
@@ -412,6 +418,13 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     if (a.ldq % 8 || a.ldk % 8 || a.ldvt % 8 || a.ldo % 4 || a.ldvt < a.l) return AID_ERR_SHAPE;
     if (a.q_fs % 8 || a.k_fs % 8 || a.vt_fs % 8 || a.o_fs % 4) return AID_ERR_SHAPE;
     if (!aligned16(a.q) || !aligned16(a.k) || !aligned16(a.vt) || !aligned16(a.out)) return AID_ERR_SHAPE;
+    if (a.bias) {
+        // one mask row covers ONE segment of l keys: the reference's fused calls fail at the broadcast of the l-wide mask against the
+        // 2 l scores of [own ; end-point] keys (interpolation.py:644-651), so there is nothing to be equal to
+        if (a.fused && a.mode != AID_MODE_PLAIN) return AID_ERR_ARG;
+        if (a.bias_fs < 0 || a.bias_hs < 0 || a.bias_rs < 0) return AID_ERR_ARG;
+        if (reinterpret_cast<uintptr_t>(a.bias) % (a.dtype == AID_DTYPE_F32 ? 4 : 2)) return AID_ERR_SHAPE;
+    }
     // algorithmic work: key segments per frame — plain 1, pure inner 1, fused inner 2,
     // pure outer 2, fused outer 3
     const int segs = a.mode == AID_MODE_PLAIN ? 1 : (a.mode == AID_MODE_INNER ? 1 : 2) + (a.fused ? 1 : 0);
@@ -448,7 +461,7 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
     // softmax over the segment's <= 3 score tiles, OUTER sides combined from the segments' maxima and row sums (aid_attn_tx.hip).  The
     // default wherever it applies (profiles/r05_attn_tx_notes.txt); ATTN_TX = 0 keeps these calls on aid_attn_kernel.  (Round 4's
     // short-stream ping-pong kernel, aid_attn_xs.hip, measured 5 - 20 % slower than aid_attn_kernel and was removed in round 5.)
-    if (aid::tune(aid::TUNE_ATTN_TX) != 0 && v2 != 1 && aid::attn_tx_supported(a)) {
+    if (!a.bias && aid::tune(aid::TUNE_ATTN_TX) != 0 && v2 != 1 && aid::attn_tx_supported(a)) {
         char nm[64];
         static const char* const mn[] = {"plain", "inner", "outer"};
         snprintf(nm, sizeof(nm), "aid_attn_tx<%s,d64,%s>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", mn[a.mode]);
@@ -459,7 +472,7 @@ int aid_attn_fwd(const AidAttnArgs* args, void* stream) {
         g_variant = a.mode == AID_MODE_OUTER ? "aid_attn_tx<d64,outer>" : a.mode == AID_MODE_INNER ? "aid_attn_tx<d64,inner>" : "aid_attn_tx<d64,plain>";
         return e == hipSuccess ? AID_OK : fail_hip(e, "aid_attn_fwd");
     }
-    const bool use_pp = aid::attn_pp_supported(a) && (alone || n_single > 0) &&
+    const bool use_pp = !a.bias && aid::attn_pp_supported(a) && (alone || n_single > 0) &&   // (a score bias: aid_attn_kernel's BIAS instantiation)
                         (v2 == 1 || (v2 < 0 && alone && dflt));
     if (use_pp) {
         char nm[64];
@@ -620,11 +633,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
     at.s = a.s; at.l = l; at.heads = a.heads; at.d = d;
     at.ldq = a.c; at.ldk = a.c; at.ldvt = cv.lp; at.ldo = a.c;
     at.q_fs = (int64_t)a.s * a.c; at.k_fs = (int64_t)l * a.c; at.vt_fs = (int64_t)a.c * cv.lp; at.o_fs = (int64_t)a.s * a.c;
-    if (cached && a.kv_cached_lt > 0) {        // keys / values padded to whole tiles by the caller (an accepted layout; no kernel needs it)
-        at.ldvt = a.kv_cached_lt;
-        at.k_fs = (int64_t)a.kv_cached_lt * a.c; at.vt_fs = (int64_t)a.c * a.kv_cached_lt;
-        at.kv_padded = 1;
-    }
+    at.bias = a.attn_bias; at.bias_fs = a.attn_bias_fs; at.bias_hs = a.attn_bias_hs; at.bias_rs = a.attn_bias_rs;
     at.mode = a.mode; at.fused = a.fused; at.begin = a.begin; at.end = a.end;
     at.accumulate = 0; at.dtype = a.dtype;
     at.softmax_scale = 1.0f / sqrtf((float)d);
@@ -640,7 +649,7 @@ int aid_processor_fwd(const AidProcessorArgs* args, void* stream) {
         AidAttnArgs ai = at;
         ai.k = kip; ai.vt = vtip; ai.k2 = nullptr; ai.vt2 = nullptr;
         ai.kv_map = a.ip_map; ai.n_kv = a.n_ip; ai.l = a.t_ip;
-        ai.kv_padded = 0;                                 // the image keys / values are laid out compactly, whatever the text keys are
+        ai.bias = nullptr;
         ai.ldk = a.c; ai.ldvt = cv.tp;
         ai.k_fs = (int64_t)a.t_ip * a.c; ai.vt_fs = (int64_t)a.c * cv.tp;
         ai.accumulate = 1; ai.out_scale = a.ip_scale; ai.frame_scale = a.ip_frame_scale;

@@ -109,7 +109,10 @@ __device__ __forceinline__ f32x16 zero16() {
 // tiles, each a global -> register -> LDS round trip behind a barrier, for 128 query rows.  Here a workgroup loads the one to
 // three segments of its (frame, head) ONCE (zero-padded to RES_KEYS keys), then every wave runs q block after q block out of
 // LDS with no barrier at all; two workgroups per CU overlap one's fill with the other's arithmetic.
-template <typename T, int D, int MODE, int NW, int QB, bool PIPE, bool RES>
+// BIAS = additive score bias (AidAttnArgs.bias: diffusers' attention_mask; the reference hands it to get_attention_scores of every
+// segment, interpolation.py:651-656, 787): a separate instantiation of the four-wave program-order kernel only, so the kernels of
+// the unmasked UNet calls carry neither its registers nor a branch.
+template <typename T, int D, int MODE, int NW, int QB, bool PIPE, bool RES, bool BIAS = false>
 __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) {
     typedef typename Vec<T>::v8 T8;
     typedef typename Vec<T>::v4 T4;
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     constexpr int VROW = RES ? RES_VLD : VLD;                   // V^T row stride in LDS (elements)
     constexpr int RSEG = RES_KEYS * KLD + DV * RES_VLD;         // elements of one resident segment: K rows, then V^T rows
     static_assert(!RES || (QB == 1 && !PIPE), "resident variant: one q block per wave, program-order tile");
+    static_assert(!BIAS || (QB == 1 && !PIPE && !RES), "score bias: program-order streaming kernel, one q block per wave");
     static_assert((RES_VLD / 8) % 2 == 1 && RSEG % 8 == 0, "resident rows: odd number of 16-B slots");
     // row of ones in V^T -> the row sums l come out of the second MFMA as a row of O^T.  A spare padded row
     // (index D) exists for d = 40 / 80; d = 64 / 160 use one eXtra 32-row block fed from a constant fragment.
@@ -216,6 +220,11 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
     const T* Vg = reinterpret_cast<const T*>(a.vt) + (int64_t)(h * D) * a.ldvt;
     const int L = a.l;
     const int Lc8 = ((L - 1) >> 3) << 3;                // first key of the last 8-key chunk holding a valid key
+    // score-bias row of this lane's query (BIAS): element j belongs to key j of whichever segment is running
+    const T* brow = nullptr;
+    if (BIAS)
+        brow = reinterpret_cast<const T*>(a.bias) + (int64_t)fr * a.bias_fs + (int64_t)h * a.bias_hs +
+               (int64_t)min(q0 + l31, a.s - 1) * a.bias_rs;
     // key bits 2<->3 swapped: MFMA row i of the score block reads LDS key row pi(i)
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
 
@@ -403,6 +412,23 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
             if (LAZY0 && st.mz) qk(std::true_type{});
             else                qk(std::false_type{});
             // lane (q, hi): sc[j][b][r] belongs to key  key0 + 32 b + 16 (r>>3) + 8 hi + (r&7)
+            if (BIAS) {
+                // scores = scale q k^T + bias (baddbmm(attention_mask, q, k^T, beta = 1, alpha = scale)); the kernel works in the log2
+                // domain.  Values below -1e30 (-inf, finfo.min of bf16) are clamped there: the key then weighs exp(-1e30) = 0 like in
+                // the reference, and a row whose keys are ALL masked averages them uniformly (the reference: uniform for finfo.min, NaN
+                // for -inf).  2-byte loads: a mask row (L elements, any L) has no alignment to offer; correctness-first path.
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {               // eight loads in flight at a time (d = 160 has no registers for 32)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int key = min(key0 + 32 * b + 16 * u + 8 * hi + e, L - 1);
+                            sc[0][b][8 * u + e] += fmaxf((float)brow[key], -1e30f) * 1.4426950408889634f;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
             if (!FULL) {
 #pragma unroll
                 for (int j = 0; j < QB; ++j)
@@ -1095,7 +1121,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D, int MODE, int NW, int QB, bool PIPE, bool RES = false>
+template <typename T, int D, int MODE, int NW, int QB, bool PIPE, bool RES = false, bool BIAS = false>
 static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
     constexpr int NREG = MODE == AID_MODE_PLAIN ? 1 : MODE == AID_MODE_INNER ? 2 : 3;
@@ -1105,13 +1131,13 @@ static hipError_t launch_variant(const AttnKParams& p, hipStream_t stream) {
     bool* done = attr_set.slot();
     if (!done) return hipErrorInvalidDevice;
     if (!*done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW, QB, PIPE, RES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&aid_attn_kernel<T, D, MODE, NW, QB, PIPE, RES, BIAS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         *done = true;
     }
     const int grid = p.nqb * p.a.n_frames * p.a.heads;
-    hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW, QB, PIPE, RES>), dim3(grid), dim3(NW * 64), smem, stream, p);
+    hipLaunchKernelGGL((aid_attn_kernel<T, D, MODE, NW, QB, PIPE, RES, BIAS>), dim3(grid), dim3(NW * 64), smem, stream, p);
     return hipGetLastError();
 }
 
@@ -1171,6 +1197,10 @@ static bool attn_res(const AidAttnArgs& a) {
 template <typename T, int D, int MODE>
 static hipError_t launch_nw(AttnKParams& p, hipStream_t stream) {
     p.q_iters = 1;
+    if (p.a.bias) {                                             // score bias: the one instantiation that reads it
+        p.nqb = (p.a.s + 127) / 128;
+        return launch_variant<T, D, MODE, 4, 1, false, false, true>(p, stream);
+    }
     if (D <= 80 && attn_res(p.a)) {
         const int nqb = (p.a.s + 127) / 128;                    // 128-row blocks (4 waves x 32 rows)
         int chunks = nqb / 2 < 1 ? 1 : nqb / 2 > RES_CHUNKS_MAX ? RES_CHUNKS_MAX : nqb / 2;
@@ -1262,7 +1292,9 @@ bool attn_head_dim_supported(int d) { return d == 40 || d == 64 || d == 80 || d 
 const char* attn_variant_name(const AidAttnArgs& a) {
     static thread_local char name[64];
     static const char* modes[] = {"plain", "inner", "outer"};
-    if (attn_res(a))
+    if (a.bias)
+        snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw4,bias>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d, modes[a.mode]);
+    else if (attn_res(a))
         snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,res>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d, modes[a.mode]);
     else if (attn_qb(a) == 2)
         snprintf(name, sizeof(name), "aid_attn<%s,d%d,%s,nw%d,qb2>", a.dtype == AID_DTYPE_F16 ? "f16" : "bf16", a.d,

@@ -164,6 +164,11 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
     const float* const K0 = reinterpret_cast<const float*>(a.k);
     const float* const V0 = reinterpret_cast<const float*>(a.vt);
 
+    // additive score bias (AidAttnArgs.bias, ABI v8): the row of this lane's query; element j goes with key j of every segment
+    const float* const brow = a.bias ? reinterpret_cast<const float*>(a.bias) + (int64_t)fr * a.bias_fs + (int64_t)h * a.bias_hs +
+                                           (int64_t)min(q, a.s - 1) * a.bias_rs
+                                     : nullptr;
+
     f32x16 res[NDB];                                               // sum over passes of weight * O^T
 #pragma unroll
     for (int d = 0; d < NDB; ++d)
@@ -199,6 +204,11 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
                 for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
                 for (int t = 0; t < D / 2; ++t) sc = mfma32f(Ks[l31 * KLD + 2 * t + hi], qf[t], sc);
+                if (brow) {                                        // scale q k^T + bias, in the log2 domain (values below -1e30 clamped, aid_attn.hip)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sc[r] += fmaxf(brow[min(t0 + key_of(r, hi), a.l - 1)], -1e30f) * 1.4426950408889634f;
+                }
                 float mx = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

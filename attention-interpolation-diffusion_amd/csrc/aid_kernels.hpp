@@ -63,7 +63,7 @@ enum Tune {
                                 // engine choice plans with 1 / n of the CUs; a hint, results never depend on it
     TUNE_GEMM_RS,               // row-stationary engine for the short-K levels (aid_gemm_rs.hip): 0 = never, 1 = wherever the shape allows;
                                 // default: wherever the shape allows AND the activation has enough row tiles to fill the device
-    TUNE_ATTN_TX,               // text-key kernel (aid_attn_tx.hip: d = 64, <= 96 keys per segment, PLAIN / OUTER): 0 = never; default: wherever supported
+    TUNE_ATTN_TX,               // text-key kernel (aid_attn_tx.hip: d = 64, <= 96 keys per segment, PLAIN / INNER / OUTER): 0 = never; default: wherever supported
     TUNE_ATTN_TX_TILES,         // > 0: 32-row tiles per wave of that kernel (sets the workgroups per (frame, head))
     TUNE_COUNT
 };
@@ -89,7 +89,7 @@ hipError_t attn_launch(const AidAttnArgs& a, hipStream_t stream, const char** va
 // d = 64 ping-pong kernel for the single-segment frames of a call (aid_attn_pp.hip); frames with more segments exit at once
 bool       attn_pp_supported(const AidAttnArgs& a);
 hipError_t attn_pp_launch(const AidAttnArgs& a, hipStream_t stream, bool multi);
-// d = 64 kernel for TEXT keys (<= 96 keys per segment resident in LDS; aid_attn_tx.hip): whole PLAIN / OUTER calls
+// d = 64 kernel for TEXT keys (<= 96 keys per segment resident in LDS; aid_attn_tx.hip): whole PLAIN / INNER / OUTER calls
 bool       attn_tx_supported(const AidAttnArgs& a);
 hipError_t attn_tx_launch(const AidAttnArgs& a, hipStream_t stream);
 bool       attn_head_dim_supported(int d);

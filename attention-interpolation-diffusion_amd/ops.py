@@ -275,22 +275,12 @@ def ln_fold(w: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch
     return wf, cs, sh
 
 
-def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, extra_rows: int = 0, padded: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, extra_rows: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """k = e @ wk.T  [F, L, C]  and  V^T = wv @ e^T  [F, C, Lp]  (Lp = L rounded up to 8) in one launch.
     ``extra_rows``: allocate that many more (uninitialised) frame rows behind the F projected ones — room for the
-    end-point frames' keys / values a rank receives from their owners (dist.EndpointExchange).
-    ``padded``: the layout of ``AidAttnArgs.kv_padded`` / ``AidProcessorArgs.kv_cached_lt`` — k [F, Lt, C], V^T [F, C, Lt] with
-    Lt = L rounded up to 64, rows / columns L .. Lt zero (an accepted layout; the kernel it was made for was removed in round 5).
-    Callers read the first L rows / columns (``k[:, :L]``, ``vt[:, :, :L]``)."""
+    end-point frames' keys / values a rank receives from their owners (dist.EndpointExchange)."""
     f, l, cc = e.shape
     c = wk.shape[0]
-    if padded:
-        lt = (l + 63) // 64 * 64
-        k = torch.zeros(f + extra_rows, lt, c, dtype=e.dtype, device=e.device)
-        vt = torch.zeros(f + extra_rows, c, lt, dtype=e.dtype, device=e.device)
-        gemm_nt([dict(a=e, b=wk, c=k, m=l, n=c, k=cc, lda=cc, ldb=cc, ldc=c, batch=f, stride_a=l * cc, stride_b=0, stride_c=lt * c),
-                 dict(a=wv, b=e, c=vt, m=c, n=l, k=cc, lda=cc, ldb=cc, ldc=lt, batch=f, stride_a=0, stride_b=l * cc, stride_c=c * lt)])
-        return k, vt
     lp = (l + 7) // 8 * 8
     k = torch.empty(f + extra_rows, l, c, dtype=e.dtype, device=e.device)
     vt = torch.empty(f + extra_rows, c, lp, dtype=e.dtype, device=e.device)
@@ -302,18 +292,44 @@ def project_kv(e: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, extra_rows: 
     return k, vt
 
 
+def score_bias_layout(bias: torch.Tensor, n: int, heads: int, s: int, l: int, dtype: torch.dtype) -> Tuple[int, int, int]:
+    """(frame stride, head stride, row stride) in elements of an additive score bias (AidAttnArgs.bias, ABI v8) given as diffusers
+    hands it around: ``[N * H, 1 | S, L]`` (``Attention.prepare_attention_mask``), ``[N, 1 | S, L]`` or ``[N, 1 | H, 1 | S, L]``."""
+    if bias.dtype != dtype:
+        raise TypeError(f"the score bias must have the activation dtype ({dtype}), got {bias.dtype}")
+    if bias.ndim == 3:
+        b0, r, ll = bias.shape
+        if b0 == n * heads and heads > 1:
+            fs, hs = heads * bias.stride(0), bias.stride(0)
+        elif b0 == n:
+            fs, hs = bias.stride(0), 0
+        else:
+            raise ValueError(f"score bias of {b0} rows for {n} frames x {heads} heads")
+        rs = bias.stride(1)
+    elif bias.ndim == 4:
+        b0, hx, r, ll = bias.shape
+        if b0 != n or hx not in (1, heads):
+            raise ValueError(f"score bias must be [N, 1 | H, 1 | S, L]; got {tuple(bias.shape)} for N = {n}, H = {heads}")
+        fs, hs, rs = bias.stride(0), (bias.stride(1) if hx > 1 else 0), bias.stride(2)
+    else:
+        raise ValueError("score bias must be a 3-D or 4-D tensor")
+    if ll != l or r not in (1, s) or (ll > 1 and bias.stride(-1) != 1):
+        raise ValueError(f"score bias must be [..., 1 | {s}, {l}] with contiguous rows; got {tuple(bias.shape)}")
+    return int(fs), int(hs), int(rs if r > 1 else 0)
+
+
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, l: int,
              mode: str = "plain", fused: bool = False, coef: Optional[torch.Tensor] = None,
              begin: int = 0, end: int = -1, out: Optional[torch.Tensor] = None,
              accumulate: bool = False, out_scale: float = 1.0,
              frame_scale: Optional[torch.Tensor] = None, kv_map: Optional[torch.Tensor] = None,
              softmax_scale: Optional[float] = None, n_plain: int = 0, seg_executed: int = 0,
-             kv_padded: bool = False, q_prescaled: bool = False) -> torch.Tensor:
+             q_prescaled: bool = False, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Interpolated attention core (see AidAttnArgs in include/aid_hip.h).
-    q [N, S, C], k [F, L, C], vt [F, C, Lp] contiguous; coef / frame_scale fp32 device [N].  ``kv_padded``: k / vt come from
-    ``project_kv(padded=True)`` ([F, Lt, C] / [F, C, Lt], zero beyond L)."""
+    q [N, S, C], k [F, L, C], vt [F, C, Lp] contiguous; coef / frame_scale fp32 device [N].  ``bias``: additive score bias
+    (diffusers' prepared attention_mask, ``score_bias_layout``); not with ``fused``."""
     lib = _lib.load()
-    _require_gpu(q, k, vt, out, coef, frame_scale, kv_map)
+    _require_gpu(q, k, vt, out, coef, frame_scale, kv_map, bias)
     dt = _dtype_code(q)
     if _dtype_code(k) != dt or _dtype_code(vt) != dt:
         raise TypeError("q, k, vt must share one dtype")
@@ -354,7 +370,9 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, 
     a.out_scale = float(out_scale)
     a.n_plain = int(n_plain)
     a.seg_executed = int(seg_executed)
-    a.kv_padded = int(bool(kv_padded))
+    if bias is not None:
+        a.bias = bias.data_ptr()
+        a.bias_fs, a.bias_hs, a.bias_rs = score_bias_layout(bias, n, heads, s, l, q.dtype)
     a.q_prescaled = int(bool(q_prescaled))              # q already holds q * softmax_scale * log2(e) (the processor path's q projection)
     with _on(q.device):
         _lib.check(lib.aid_attn_fwd(C.byref(a), _stream()), "aid_attn_fwd")
@@ -390,7 +408,8 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
                   ln: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor], float]] = None,
                   residual: Optional[torch.Tensor] = None, seg_executed: int = 0,
                   ip: Optional[dict] = None, ln_folded: Optional[tuple] = None,
-                  kv_cached: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+                  kv_cached: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                  attn_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One whole processor call: y = to_out(AID-attention(to_q(x), to_k(ctx), to_v(ctx)))
     in three launches (grouped q/k/V^T GEMM, attention core, out-proj GEMM).
     ``ln = (gamma, beta, eps)`` computes on LayerNorm(x); ``residual`` is added to the result (the transformer
@@ -402,10 +421,12 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
     ``ln_fold``, wk' / wv' None for cross-attention, const fp32 [6, C] = colsum_q, shift_q, colsum_k, shift_k, colsum_v,
     shift_v): only the row statistics of x are computed, LayerNorm(x) is never written.
     ``kv_cached`` = (k, vt) from ``project_kv(ctx, wk, wv)``: the step-invariant keys / values of a cross-attention layer,
-    projected once by the caller; the call then projects the queries only."""
+    projected once by the caller; the call then projects the queries only.
+    ``attn_bias``: additive score bias of the (text) attention — diffusers' prepared attention_mask (AidProcessorArgs.attn_bias,
+    ``score_bias_layout``); the library refuses it together with ``fused`` or ``ip`` (the reference fails there, aid_hip.h)."""
     lib = _lib.load()
     ipt = ip or {}
-    dev = _require_gpu(x, ctx, wq, wk, wv, wo, bo, coef, ctx_map, out, residual, *(ln[:2] if ln else ()),
+    dev = _require_gpu(x, ctx, wq, wk, wv, wo, bo, coef, ctx_map, out, residual, attn_bias, *(ln[:2] if ln else ()),
                        ipt.get("tokens"), ipt.get("wk"), ipt.get("wv"), ipt.get("map"), ipt.get("frame_scale"))
     dt = _dtype_code(x)
     for t_ in (ctx, wq, wk, wv, wo, bo):
@@ -479,16 +500,16 @@ def processor_fwd(x: torch.Tensor, ctx: Optional[torch.Tensor], wq: torch.Tensor
             raise ValueError("cached keys / values belong to a cross-attention call")
         kc, vc = kv_cached
         _require_gpu(kc, vc)
-        lp, lt = (ctx.shape[1] + 7) // 8 * 8, (ctx.shape[1] + 63) // 64 * 64
+        lp = (ctx.shape[1] + 7) // 8 * 8
         ok = kc.dtype == x.dtype and vc.dtype == x.dtype and kc.is_contiguous() and vc.is_contiguous() \
-            and kc.shape[0] >= ctx.shape[0] and vc.shape[0] >= ctx.shape[0]
-        compact = ok and tuple(kc.shape[1:]) == (ctx.shape[1], c) and tuple(vc.shape[1:]) == (c, lp)
-        padded = ok and tuple(kc.shape[1:]) == (lt, c) and tuple(vc.shape[1:]) == (c, lt) and mode != "inner"
-        if not (compact or padded):
-            raise ValueError("kv_cached must be (k [n_ctx, L, C], vt [n_ctx, C, round_up(L, 8)]) or, padded to whole key tiles, "
-                             "(k [n_ctx, Lt, C], vt [n_ctx, C, Lt]) with Lt = round_up(L, 64) — as project_kv returns them")
+            and kc.shape[0] >= ctx.shape[0] and vc.shape[0] >= ctx.shape[0] \
+            and tuple(kc.shape[1:]) == (ctx.shape[1], c) and tuple(vc.shape[1:]) == (c, lp)
+        if not ok:
+            raise ValueError("kv_cached must be (k [n_ctx, L, C], vt [n_ctx, C, round_up(L, 8)]) as project_kv returns them")
         a.k_cached, a.vt_cached = kc.data_ptr(), vc.data_ptr()
-        a.kv_cached_lt = 0 if compact else lt
+    if attn_bias is not None:
+        a.attn_bias = attn_bias.data_ptr()
+        a.attn_bias_fs, a.attn_bias_hs, a.attn_bias_rs = score_bias_layout(attn_bias, n, heads, s, a.l, x.dtype)
     a.cu_share = current_cu_share()
     nbytes = lib.aid_processor_workspace_bytes(C.byref(a))
     with _on(dev):

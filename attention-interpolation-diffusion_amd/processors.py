@@ -204,10 +204,7 @@ def _shared_context(cache: Dict, ctx_index, ctx: torch.Tensor, batch: int):
 # shared pre/post-processing of a processor call (the non-attention lines of the reference bodies)
 # ---------------------------------------------------------------------------------------------
 def _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb):
-    """interpolation.py:586-611 / 616-621.  Returns (residual, x[N,S,C], ctx or None, restore-4d info)."""
-    if attention_mask is not None:
-        raise NotImplementedError("attention_mask is not supported by the HIP path "
-                                  "(UNet attention of SD / SDXL never passes one)")
+    """interpolation.py:586-611 / 616-621.  Returns (residual, x[N,S,C], ctx or None, restore-4d info, prepared mask or None)."""
     residual = hidden_states
     if getattr(attn, "spatial_norm", None) is not None:
         hidden_states = attn.spatial_norm(hidden_states, temb)
@@ -216,11 +213,35 @@ def _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb):
         b, ch, hh, ww = hidden_states.shape
         shape4 = (b, ch, hh, ww)
         hidden_states = hidden_states.view(b, ch, hh * ww).transpose(1, 2)
+    if attention_mask is not None:
+        # interpolation.py:598-606: the mask is prepared for the KEY sequence (the context's length, or the hidden states')
+        batch_size, sequence_length, _ = (hidden_states.shape if encoder_hidden_states is None
+                                          else encoder_hidden_states.shape)
+        attention_mask = attn.prepare_attention_mask(attention_mask, sequence_length, batch_size)
     if getattr(attn, "group_norm", None) is not None:
         hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
     if encoder_hidden_states is not None and getattr(attn, "norm_cross", None):
         encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
-    return residual, hidden_states.contiguous(), encoder_hidden_states, shape4
+    return residual, hidden_states.contiguous(), encoder_hidden_states, shape4, attention_mask
+
+
+def _score_bias(mask, x: torch.Tensor, l: int, fused: bool, what: str):
+    """The prepared attention_mask as the library's additive score bias (AidAttnArgs.bias).  The reference adds it to the scores of
+    every key segment through ``baddbmm(attention_mask, q, k^T, beta=1, alpha=scale)`` (App. A; interpolation.py:651-656, 787): a
+    FUSED call — keys ``[own ; end-point]``, 2 L wide — fails there at the broadcast of the L-wide mask, and so does this one."""
+    if mask is None:
+        return None
+    if not torch.is_tensor(mask) or mask.dtype != x.dtype:
+        raise RuntimeError(f"attention_mask must be a {x.dtype} tensor like the hidden states (the reference adds it with baddbmm), "
+                           f"got {getattr(mask, 'dtype', type(mask))}")
+    if fused:
+        raise RuntimeError(f"The expanded size of the tensor ({2 * l}) must match the existing size ({mask.shape[-1]}) at "
+                           f"non-singleton dimension 2 ({what}: an attention_mask covers one key segment; the fused "
+                           "[own ; end-point] keys are twice as long — the reference fails at the same broadcast)")
+    if mask.shape[-1] != l:
+        raise RuntimeError(f"The expanded size of the tensor ({l}) must match the existing size ({mask.shape[-1]}) at "
+                           "non-singleton dimension 2 (attention_mask vs keys)")
+    return mask if mask.stride(-1) == 1 or mask.shape[-1] == 1 else mask.contiguous()
 
 
 def _epilogue(attn, hidden_states, residual, shape4):
@@ -317,23 +338,15 @@ def _vkey(t: torch.Tensor):
     return None if v is None else (t.data_ptr(), v)
 
 
-def _kv_padded_layout() -> bool:
-    """The tile-padded layout of the cached text keys / values (``AidProcessorArgs.kv_cached_lt``) served round 4's short-stream
-    kernel, removed in round 5; the cache keeps the compact layout.  (The library still accepts the padded layout.)"""
-    return False
-
-
-def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tensor, padded: bool = False):
+def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tensor):
     """(k [n_ctx, L, C], vt [n_ctx, C, Lp]) of the distinct contexts ``ctx`` derived from the caller's tensor ``ehs``
-    (``idx`` = frame -> context map or None), from the cache or projected now; None where caching does not apply.
-    ``padded`` (every mode but INNER, whose interpolated keys are laid out compactly): rows / columns up to the next multiple of
-    64 keys, zero beyond L (``AidProcessorArgs.kv_cached_lt``; an accepted layout that no kernel requires since round 5)."""
+    (``idx`` = frame -> context map or None), from the cache or projected now; None where caching does not apply."""
     if not TEXT_KV_CACHE or ehs is None or not torch.is_tensor(ehs):
         return None
     ks = (_vkey(ehs), _vkey(wk), _vkey(wv))
     if None in ks:
         return None
-    key = ks + (tuple(ehs.shape), ehs.dtype, tuple(idx) if idx is not None else None, bool(padded))
+    key = ks + (tuple(ehs.shape), ehs.dtype, tuple(idx) if idx is not None else None)
     try:
         per = _KV_CACHE.get(attn)
         if per is None:
@@ -343,7 +356,7 @@ def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tens
         return None
     hit = per.get(key)
     if hit is None:
-        k, vt = ops.project_kv(ctx, wk, wv, padded=padded)
+        k, vt = ops.project_kv(ctx, wk, wv)
         for old in [kk for kk in per if kk[0][0] == key[0][0] and kk[3:] == key[3:]]:
             per.pop(old, None)            # the same tensor at an older version (or with replaced weights)
 
@@ -365,9 +378,11 @@ def _plain_sublayer_ok(attn, hidden_states) -> bool:
 
 def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidden_states,
               attention_mask, temb, mode: str, ctx_index=None, ln=None, add_to=None, ln_folded=None):
-    residual, x, ctx, shape4 = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+    residual, x, ctx, shape4, mask = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
     ehs = ctx                                         # the tensor the caller holds on to across steps (cache key)
     wq, wk, wv, wo, bo = _weights(attn)
+    bias = _score_bias(mask, x, x.shape[1] if ctx is None else ctx.shape[1], mode != "plain" and proc.is_fused,
+                       type(proc).__name__)
     coef = vals = None
     if mode != "plain":
         coef, vals = proc._coef_state(x.device, x.dtype, x.shape[0])
@@ -377,6 +392,8 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
     ctx_index = proc.ctx_index if ctx_index is None else ctx_index
     exchange = getattr(proc, "endpoint_exchange", None)
     if exchange is not None and mode != "plain":
+        if bias is not None:
+            raise NotImplementedError("the end-point exchange layout takes no attention_mask")
         if ln is not None or add_to is not None:
             raise NotImplementedError("the end-point exchange layout runs the plain processor call (no sublayer fusion)")
         n = x.shape[0]
@@ -427,7 +444,7 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
         ctx2, ctx_map, idx2 = _shared_context(proc._ctx_cache, full_map, full, n + 2)
         y = ops.processor_fwd(x, ctx2, wq, wk, wv, wo, bo, attn.heads, mode=mode, fused=proc.is_fused, coef=coef,
                               begin=nctx, end=nctx + 1, ctx_map=ctx_map[:n], n_plain=proc.plain_tail,
-                              kv_cached=_text_kv(attn, full, ctx2, idx2, wk, wv, padded=mode != "inner" and _kv_padded_layout()))
+                              kv_cached=_text_kv(attn, full, ctx2, idx2, wk, wv))
         return _epilogue(attn, y, residual, shape4)
     if ctx is not None and ctx_index is not None:
         ctx, ctx_map, idx = _shared_context(proc._ctx_cache, ctx_index, ctx, x.shape[0])
@@ -440,7 +457,7 @@ def _run_text(proc: InterpolatedAttnProcessor, attn, hidden_states, encoder_hidd
                           begin=begin, end=end, ctx_map=ctx_map,
                           n_plain=proc.plain_tail if mode != "plain" else 0, ln=ln, residual=add_to, ln_folded=ln_folded,
                           seg_executed=ops.executed_segments(mode, fused, vals, x.shape[0], idx, begin, end),
-                          kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv, padded=mode != "inner" and _kv_padded_layout()) if ctx is not None else None)
+                          kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv) if ctx is not None else None, attn_bias=bias)
     return _epilogue(attn, y, residual, shape4)
 
 
@@ -467,14 +484,14 @@ class HipAttnProcessor:
             ctx = ctx.contiguous()
         return ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map,
                                  ln=_ln_of(norm), residual=x, ln_folded=_ln_folded(attn, norm, ctx is not None),
-                                 kv_cached=_text_kv(attn, encoder_hidden_states, ctx, idx, wk, wv, padded=_kv_padded_layout())
-                                 if ctx is not None else None)
+                                 kv_cached=_text_kv(attn, encoder_hidden_states, ctx, idx, wk, wv) if ctx is not None else None)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  *args, ctx_index=None, **kwargs):
-        residual, x, ctx, shape4 = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+        residual, x, ctx, shape4, mask = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         ehs = ctx
         wq, wk, wv, wo, bo = _weights(attn)
+        bias = _score_bias(mask, x, x.shape[1] if ctx is None else ctx.shape[1], False, "HipAttnProcessor")
         ctx_map = idx = None
         ctx_index = self.ctx_index if ctx_index is None else ctx_index
         if ctx is not None and ctx_index is not None:
@@ -482,7 +499,7 @@ class HipAttnProcessor:
         elif ctx is not None:
             ctx = ctx.contiguous()
         y = ops.processor_fwd(x, ctx, wq, wk, wv, wo, bo, attn.heads, mode="plain", ctx_map=ctx_map,
-                              kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv, padded=_kv_padded_layout()) if ctx is not None else None)
+                              kv_cached=_text_kv(attn, ehs, ctx, idx, wk, wv) if ctx is not None else None, attn_bias=bias)
         return _epilogue(attn, y, residual, shape4)
 
 
@@ -601,8 +618,13 @@ class HipIPAdapterAttnProcessor(nn.Module):
         if ip_adapter_masks is not None:
             raise NotImplementedError("ip_adapter_masks are not supported by the HIP path")
         text, ip = _split_ip(encoder_hidden_states, self.num_tokens)
-        residual, x, text, shape4 = _prologue(attn, hidden_states, text, attention_mask, temb)
+        residual, x, text, shape4, mask = _prologue(attn, hidden_states, text, attention_mask, temb)
         wq, wk, wv, wo, bo = _weights(attn)
+        # diffusers' IPAdapterAttnProcessor2_0 masks the TEXT attention only (the image branch runs with attn_mask=None)
+        bias = _score_bias(mask, x, x.shape[1] if text is None else text.shape[1], False, "HipIPAdapterAttnProcessor")
+        if bias is not None and ip is not None and float(self.scale[0]) != 0.0:
+            raise NotImplementedError("attention_mask together with image embeddings: the one-call form has no mask for the text "
+                                      "branch alone (AidProcessorArgs.attn_bias is refused with ip)")
         branch = None
         if ip is not None and float(self.scale[0]) != 0.0:
             rows = _ip_token_rows(ip)
@@ -613,7 +635,7 @@ class HipIPAdapterAttnProcessor(nn.Module):
             branch = dict(tokens=tokens, wk=self.to_k_ip[0].weight, wv=self.to_v_ip[0].weight, mode="plain",
                           scale=float(self.scale[0]))
         y = ops.processor_fwd(x, None if text is None else text.contiguous(), wq, wk, wv, wo, bo, attn.heads,
-                              mode="plain", ip=branch)
+                              mode="plain", ip=branch, attn_bias=bias)
         return _epilogue(attn, y, residual, shape4)
 
 
@@ -663,7 +685,13 @@ class _IPBase(InterpolatedAttnProcessor):
 
     def _call(self, attn, hidden_states, encoder_hidden_states, attention_mask, temb, mode, branch_of):
         text, ip = _split_ip(encoder_hidden_states, self.num_tokens)
-        residual, x, text, shape4 = _prologue(attn, hidden_states, text, attention_mask, temb)
+        residual, x, text, shape4, mask = _prologue(attn, hidden_states, text, attention_mask, temb)
+        if mask is not None:
+            # the reference hands the text-length mask to the IMAGE attention too (interpolation.py:141-143, 191-193, 352-359,
+            # 525): T image tokens against an L-wide mask fails at the broadcast unless T == L, and fused text keys fail first
+            raise RuntimeError(f"The expanded size of the tensor must match the existing size ({mask.shape[-1]}) at non-singleton "
+                               "dimension 2: the IP processors apply the text attention_mask to the image-token scores as well "
+                               "(interpolation.py:141-143, 352-359) — the reference fails at that broadcast; pass no mask")
         n = self._frames(x)
         wq, wk, wv, wo, bo = _weights(attn)
         coef, vals = self._coef_state(x.device, x.dtype, x.shape[0])

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AID_ABI_VERSION 7
+#define AID_ABI_VERSION 8
 
 /* element types of activations / weights (accumulation is always fp32) */
 #define AID_DTYPE_F16  0
@@ -44,7 +44,7 @@ extern "C" {
 /* ABI v7: float32 tensors in and out, float32 arithmetic (v_mfma_f32_32x32x2_f32, the f32 vector rate) — the reference's own default
  * for SD1.x (gradio_src/app.py:62, 414) and its CPU path.  aid_gemm_nt, aid_attn_fwd, aid_lerp_kv and aid_processor_fwd take it
  * (probabilities are then not rounded before the PV product, like the reference's float32 get_attention_scores); the LayerNorm
- * entry points and the ln_* / residual-fusion options of aid_processor_fwd are 16-bit only (AID_ERR_DTYPE). */
+ * entry points and the ln_* options of aid_processor_fwd are 16-bit only (AID_ERR_DTYPE); `residual` works with every dtype. */
 #define AID_DTYPE_F32  2
 
 /* image branch of the IP-Adapter processors (AidProcessorArgs.ip_mode) */
@@ -185,10 +185,20 @@ typedef struct AidAttnArgs {
     int32_t seg_executed;        /* profiling accounting: (frame, key segment) passes this launch really runs —  */
                                  /* fused END-POINT frames and coefficient-0/1 sides run fewer than the          */
                                  /* algorithmic count; 0 = unknown (reported equal to the algorithmic count)     */
-    int32_t kv_padded;           /* 1: every row of k holds at least round_up(l, 64) key rows (k_fs >= that * ldk) and every row   */
-                                 /* of vt at least round_up(l, 64) columns (ldvt >= that); key rows l .. are FINITE, value columns */
-                                 /* l .. are ZERO.  A layout promise the caller may make (ABI v6; was reserved0); no kernel depends */
-                                 /* on it since round 5 (the short-stream kernel it served was removed); 0: no such guarantee      */
+    int32_t reserved0;
+    /* ABI v8 — additive score bias (NULL: none): diffusers' attention_mask after Attention.prepare_attention_mask, which every  */
+    /* reference processor hands to get_attention_scores (interpolation.py:115-117, 604-606, 651, 738-739, 787):              */
+    /*     scores = softmax_scale * Q K^T + bias        (baddbmm(attention_mask, q, k^T, beta = 1, alpha = scale))              */
+    /* bias element (frame f, head h, query row r, key j) at  bias + f * bias_fs + h * bias_hs + r * bias_rs + j  (elements of    */
+    /* the operand dtype; bias_hs = 0: one mask for all heads, bias_rs = 0: one row for all queries — the [B * H, 1, L] tensor   */
+    /* of prepare_attention_mask is bias_fs = H * L, bias_hs = L, bias_rs = 0).  It covers ONE key segment of l keys: a call     */
+    /* whose frames attend to [own ; end-point] keys (fused) is refused (AID_ERR_ARG) — the reference fails there too, at the    */
+    /* broadcast of an l-wide mask against 2 l scores.  INNER / OUTER apply it to the begin, end and interpolated segments       */
+    /* alike.  Strides are multiples of 1 element; the base pointer needs the operand dtype's alignment only.  v7's kv_padded    */
+    /* (a layout promise no kernel depended on) is gone.                                                                         */
+    const void* bias;
+    int64_t bias_fs;
+    int32_t bias_hs, bias_rs;
 } AidAttnArgs;
 
 int aid_attn_fwd(const AidAttnArgs* args /* host */, void* stream);
@@ -260,10 +270,7 @@ typedef struct AidProcessorArgs {
     float   ip_scale;
     int32_t ip_begin, ip_end;    /* AID_IP_SAME: image rows of the end-point frames           */
     int32_t seg_executed;        /* accounting, see AidAttnArgs.seg_executed (text launch only) */
-    int32_t kv_cached_lt;        /* layout of k_cached / vt_cached.  0: compact — k_cached [n_ctx, l, c], vt_cached [n_ctx, c, lp]  */
-                                 /* (lp = l rounded up to 8).  > 0: PADDED to whole key tiles — k_cached [n_ctx, lt, c], vt_cached  */
-                                 /* [n_ctx, c, lt] with lt = kv_cached_lt >= round_up(l, 64), key rows l .. lt finite, value        */
-                                 /* columns l .. lt ZERO (AidAttnArgs.kv_padded; ABI v6, was reserved0).  Not with AID_MODE_INNER.  */
+    int32_t reserved2;           /* (v6 / v7: kv_cached_lt, a tile-padded layout of the cached keys that no kernel needed; removed in v8) */
     /* ---- folded LayerNorm (ln_eps > 0 and ln_wq != NULL): the call runs aid_ln_stats on x instead of aid_layernorm and  */
     /* projects x with the folded weights (aid_ln_fold of wq / wk / wv with ln_gamma / ln_beta; wk / wv only for           */
     /* self-attention, a cross-attention ctx is not normalised).  ln_const: fp32 [6, c] = colsum_q, shift_q, colsum_k,     */
@@ -281,6 +288,10 @@ typedef struct AidProcessorArgs {
     const void*  vt_cached;
     int32_t      cu_share;       /* ABI v7: see AidGemmProblem.cu_share — handed to every GEMM launch of the call            */
     int32_t      reserved1;
+    /* ABI v8: additive score bias of the text attention (attention_mask), see AidAttnArgs.bias; not with `fused`, not with `ip` */
+    const void*  attn_bias;
+    int64_t      attn_bias_fs;
+    int32_t      attn_bias_hs, attn_bias_rs;
 } AidProcessorArgs;
 
 size_t aid_processor_workspace_bytes(const AidProcessorArgs* args /* host */);

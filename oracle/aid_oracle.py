@@ -120,10 +120,14 @@ def merge_heads(t: np.ndarray) -> np.ndarray:
     return t.transpose(0, 2, 1, 3).reshape(b, l, h * d)
 
 
-def softmax_attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: float) -> np.ndarray:
-    """get_attention_scores + bmm (interpolation.py:651-652): softmax(q k^T * scale) v,
-    all operands already head-split [B, H, *, d]."""
+def softmax_attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: float,
+                      mask: Optional[np.ndarray] = None) -> np.ndarray:
+    """get_attention_scores + bmm (interpolation.py:651-652): softmax(q k^T * scale [+ mask]) v,
+    all operands already head-split [B, H, *, d]; ``mask`` = the prepared attention_mask as [B, H | 1, S | 1, L],
+    added to the scaled scores (diffusers' ``baddbmm(attention_mask, q, k^T, beta=1, alpha=scale)``, App. A)."""
     s = (q @ k.transpose(0, 1, 3, 2)) * q.dtype.type(scale)
+    if mask is not None:
+        s = s + mask.astype(s.dtype)
     s = s - s.max(axis=-1, keepdims=True)
     p = np.exp(s)
     p /= p.sum(axis=-1, keepdims=True)
@@ -145,8 +149,11 @@ def _cvec(coef: np.ndarray, dt) -> np.ndarray:
 # --------------------------------------------------------------------------
 def attn_core(q: np.ndarray, k: np.ndarray, v: np.ndarray, heads: int, scale: float,
               mode: str, is_fused: bool, coef: Optional[np.ndarray],
-              begin: int = 0, end: int = -1) -> np.ndarray:
+              begin: int = 0, end: int = -1, mask: Optional[np.ndarray] = None) -> np.ndarray:
     """Interpolated attention on projected tensors.  mode in {plain, outer, inner}.
+    ``mask``: the prepared attention_mask, [N * H | N, 1 | S, L] (``prepare_attention_mask``) or [N, H | 1, S | 1, L]; the
+    reference adds the SAME mask to the begin and the end side (interpolation.py:651-656) and to the interpolated keys (:787);
+    with ``is_fused`` its L-wide mask meets 2 L scores and the broadcast fails — so does this function.
 
     outer: interpolation.py:626-664;  inner: interpolation.py:760-790;
     plain: the AttnProcessor2_0 fallback (interpolation.py:581-584).
@@ -157,8 +164,15 @@ def attn_core(q: np.ndarray, k: np.ndarray, v: np.ndarray, heads: int, scale: fl
     dt = q.dtype
     end = end % k.shape[0]
     qh = split_heads(q, heads)
+    if mask is not None:
+        mask = np.asarray(mask)
+        if mask.ndim == 3:                              # [N * H, R, L] -> [N, H, R, L];  [N, R, L] -> [N, 1, R, L]
+            mask = mask.reshape(n, -1, mask.shape[1], mask.shape[2])
+        if is_fused and mode != "plain":
+            raise RuntimeError(f"The expanded size of the tensor ({2 * k.shape[1]}) must match the existing size "
+                               f"({mask.shape[-1]}) at non-singleton dimension 2")
     if mode == "plain":
-        return merge_heads(softmax_attention(qh, split_heads(k, heads), split_heads(v, heads), scale))
+        return merge_heads(softmax_attention(qh, split_heads(k, heads), split_heads(v, heads), scale, mask))
     c = _cvec(coef, dt)
     kb, ke = _rep(k, begin, n), _rep(k, end, n)
     vb, ve = _rep(v, begin, n), _rep(v, end, n)
@@ -171,8 +185,8 @@ def attn_core(q: np.ndarray, k: np.ndarray, v: np.ndarray, heads: int, scale: fl
             veh = np.concatenate([vh, veh], axis=-2)
             kbh = np.concatenate([kh, kbh], axis=-2)
             vbh = np.concatenate([vh, vbh], axis=-2)
-        o_end = merge_heads(softmax_attention(qh, keh, veh, scale))
-        o_beg = merge_heads(softmax_attention(qh, kbh, vbh, scale))
+        o_end = merge_heads(softmax_attention(qh, keh, veh, scale, mask))
+        o_beg = merge_heads(softmax_attention(qh, kbh, vbh, scale, mask))
         return (1 - c) * o_beg + c * o_end              # interpolation.py:662-664
     if mode == "inner":
         kc = (1 - c) * kb + c * ke                      # interpolation.py:772-775
@@ -181,7 +195,7 @@ def attn_core(q: np.ndarray, k: np.ndarray, v: np.ndarray, heads: int, scale: fl
         if is_fused:                                   # interpolation.py:781-785
             kch = np.concatenate([split_heads(k, heads), kch], axis=-2)
             vch = np.concatenate([split_heads(v, heads), vch], axis=-2)
-        return merge_heads(softmax_attention(qh, kch, vch, scale))
+        return merge_heads(softmax_attention(qh, kch, vch, scale, mask))
     raise ValueError(mode)
 
 
@@ -211,22 +225,22 @@ def layer_norm(x: np.ndarray, gamma: Optional[np.ndarray] = None, beta: Optional
     return y
 
 
-def plain_attention(x, ctx, w: AttnWeights) -> np.ndarray:
+def plain_attention(x, ctx, w: AttnWeights, mask=None) -> np.ndarray:
     """De-activated processors: original AttnProcessor2_0 (interpolation.py:581-584)."""
     q, k, v = _project(x, ctx, w)
-    return _out(attn_core(q, k, v, w.heads, w.scale, "plain", False, None), w)
+    return _out(attn_core(q, k, v, w.heads, w.scale, "plain", False, None, mask=mask), w)
 
 
-def outer_attention(x, ctx, w: AttnWeights, coef, is_fused: bool) -> np.ndarray:
-    """OuterInterpolatedAttnProcessor.__call__, interpolation.py:573-679."""
+def outer_attention(x, ctx, w: AttnWeights, coef, is_fused: bool, mask=None) -> np.ndarray:
+    """OuterInterpolatedAttnProcessor.__call__, interpolation.py:573-679 (``mask``: the prepared attention_mask, :604-606)."""
     q, k, v = _project(x, ctx, w)
-    return _out(attn_core(q, k, v, w.heads, w.scale, "outer", is_fused, coef), w)
+    return _out(attn_core(q, k, v, w.heads, w.scale, "outer", is_fused, coef, mask=mask), w)
 
 
-def inner_attention(x, ctx, w: AttnWeights, coef, is_fused: bool) -> np.ndarray:
-    """InnerInterpolatedAttnProcessor.__call__, interpolation.py:707-804."""
+def inner_attention(x, ctx, w: AttnWeights, coef, is_fused: bool, mask=None) -> np.ndarray:
+    """InnerInterpolatedAttnProcessor.__call__, interpolation.py:707-804 (``mask``: :738-739, 787)."""
     q, k, v = _project(x, ctx, w)
-    return _out(attn_core(q, k, v, w.heads, w.scale, "inner", is_fused, coef), w)
+    return _out(attn_core(q, k, v, w.heads, w.scale, "inner", is_fused, coef, mask=mask), w)
 
 
 # ---- IP-Adapter variants.  The reference hard-wires a batch of 3 (SURVEY.md App. D5): ``expand(3, ...)``, ``[::3]``,

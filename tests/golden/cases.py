@@ -32,6 +32,9 @@ class TextCase:
     alpha: float = 3.0
     beta: float = 3.0
     seed: int = 0
+    # attention_mask handed to the processor: None, "key" = additive [N, 1, L] (what diffusers' UNet builds from a boolean
+    # keep-mask: (1 - keep) * -10000, unsqueeze(1)), "full" = additive [N, S, L] (one row per query)
+    mask: Optional[str] = None
 
     @property
     def c(self) -> int:
@@ -82,6 +85,36 @@ def _text_cases() -> List[TextCase]:
     for mode in ("pure_outer", "pure_inner"):
         sd += 1
         cases.append(TextCase(f"n5_d64_s_{mode}", 5, 16, 2, 64, False, mode, alpha=25, beta=25, seed=sd))
+    # ---- round 6: the head counts of the real stacks, the 16-frame schedule of configs[3], a multi-tile key
+    # stream per mode, and the attention_mask protocol (next #8).  Small S keeps the fixtures small; the widths are the real ones.
+    sd = 200
+    for heads, d, s_, pairs in ((8, 40, 24, (("s", "fused_inner"), ("x", "fused_outer"))),          # SD1.5 level 0: C = 320
+                                (10, 64, 16, (("s", "fused_outer"), ("x", "fused_inner"))),         # SDXL level 1: C = 640
+                                (20, 64, 8, (("s", "fused_outer"), ("x", "pure_outer")))):          # SDXL level 2: C = 1280
+        for kind, mode in pairs:
+            sd += 1
+            cases.append(TextCase(f"h{heads}_d{d}_{kind}_{mode}", 3, s_, heads, d, kind == "x", mode, cc=64, t=0.4, seed=sd))
+    # N = 16, Beta(50, 50): the schedule of BASELINE configs[3]; tests/test_dist_gloo.py and the GPU suite also hold the per-rank
+    # shard batches of dist.frame_shard against ROWS of these reference outputs
+    for kind, mode in (("s", "fused_outer"), ("s", "fused_inner"), ("x", "fused_outer")):
+        sd += 1
+        cases.append(TextCase(f"n16_d64_{kind}_{mode}", 16, 12, 2, 64, kind == "x", mode, cc=64, alpha=50, beta=50, seed=sd))
+    # S = L = 256 self-attention (four 64-key tiles per segment), one case per mode
+    for mode in ("pure_outer", "fused_outer", "pure_inner", "fused_inner", "plain"):
+        sd += 1
+        cases.append(TextCase(f"s256_d40_s_{mode}", 3, 256, 1, 40, False, mode, t=0.6, seed=sd))
+    # attention_mask (interpolation.py:604-606, 651-656, 738-739, 787): the modes whose keys are ONE segment wide
+    for name, n, s_, h, d, cross, mode, kw in (
+            ("mask_n3_d40_x_pure_outer", 3, 40, 2, 40, True, "pure_outer", dict(t=0.3, mask="key")),
+            ("mask_n3_d40_x_pure_inner", 3, 40, 2, 40, True, "pure_inner", dict(t=0.3, mask="key")),
+            ("mask_n3_d40_s_pure_outer", 3, 40, 2, 40, False, "pure_outer", dict(t=0.7, mask="key")),
+            ("mask_n3_d40_s_pure_inner", 3, 40, 2, 40, False, "pure_inner", dict(t=0.7, mask="key")),
+            ("mask_n7_d64_x_pure_outer", 7, 33, 2, 64, True, "pure_outer", dict(cc=64, mask="key")),
+            ("mask_n5_d64_s_pure_inner_rows", 5, 72, 2, 64, False, "pure_inner", dict(alpha=25, beta=25, mask="full")),
+            ("mask_n3_d80_x_plain", 3, 24, 1, 80, True, "plain", dict(mask="key")),
+            ("mask_n3_d160_s_plain_rows", 3, 24, 1, 160, False, "plain", dict(mask="full"))):
+        sd += 1
+        cases.append(TextCase(name, n, s_, h, d, cross, mode, seed=sd, **kw))
     return cases
 
 
@@ -128,6 +161,14 @@ def text_inputs(case: TextCase) -> Dict[str, np.ndarray]:
     )
     if case.cross:
         inp["ctx"] = randn(rs, case.n, case.l, cc)
+    if case.mask is not None:
+        # boolean keep-mask (about a third of the keys dropped, key 0 always kept) -> the additive fp32 tensor diffusers' UNet hands
+        # to Attention.forward: (1 - keep) * -10000.0, [N, 1, L] ("key") or [N, S, L] ("full")
+        l = case.l if case.cross else case.s
+        rows = 1 if case.mask == "key" else case.s
+        keep = rs.random_sample((case.n, rows, l)) > 0.35
+        keep[..., 0] = True
+        inp["mask"] = ((1.0 - keep.astype(np.float32)) * -10000.0).astype(np.float32)
     return inp
 
 

@@ -257,22 +257,3 @@ def test_processor_path(kind):
     y = proc(attn, x, encoder_hidden_states=ctx)
     assert "aid_attn_tx" in ops.last_attn_variant(), ops.last_attn_variant()
     assert torch.equal(y, proc(attn, x, encoder_hidden_states=ctx)) and rel_l2(to_np64(y), ref) < TOL[dtype]
-
-
-def test_padded_text_cache_layout_is_still_accepted():
-    """ops.project_kv(padded=True) / AidAttnArgs.kv_padded (ABI v6): rows / columns up to a multiple of 64 keys, zero beyond L — the
-    layout round 4's short-stream kernel needed.  That kernel is gone; the layout stays a valid way to hand keys / values over."""
-    dtype, f, l, cc, c = torch.bfloat16, 3, 77, 256, 192
-    g = torch.Generator().manual_seed(1)
-    e = torch.randn(f, l, cc, generator=g).to(dtype).to(DEV)
-    wk = (torch.randn(c, cc, generator=g) / 16).to(dtype).to(DEV)
-    wv = (torch.randn(c, cc, generator=g) / 16).to(dtype).to(DEV)
-    k, vt = ops.project_kv(e, wk, wv)
-    kp, vtp = ops.project_kv(e, wk, wv, padded=True)
-    assert tuple(kp.shape) == (f, 128, c) and tuple(vtp.shape) == (f, c, 128)
-    assert torch.equal(kp[:, :l], k) and torch.equal(vtp[:, :, :l], vt[:, :, :l])
-    assert not kp[:, l:].any() and not vtp[:, :, l:].any()
-    q = torch.randn(f, 200, c, generator=g).to(dtype).to(DEV)
-    o_pad = ops.attn_fwd(q, kp, vtp, 3, l=l, mode="plain", kv_padded=True)
-    assert ops.last_attn_variant() == "aid_attn_tx<d64,plain>"
-    assert torch.equal(o_pad, ops.attn_fwd(q, k, vt, 3, l=l, mode="plain"))

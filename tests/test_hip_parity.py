@@ -320,8 +320,11 @@ def test_text_processors_vs_reference_goldens(case, dtype):
     attn = make_attn(aid_amd, inp, case.heads, case.cc if case.cross else None, dtype, DEV)
     x = torch.from_numpy(inp["x"]).to(dtype).to(DEV)
     ctx = torch.from_numpy(inp["ctx"]).to(dtype).to(DEV) if case.cross else None
-    y = _text_proc(case)(attn, x, encoder_hidden_states=ctx)
+    mask = torch.from_numpy(inp["mask"]).to(dtype).to(DEV) if case.mask is not None else None     # additive [N, 1 | S, L]
+    y = _text_proc(case)(attn, x, encoder_hidden_states=ctx, attention_mask=mask)
     assert y.shape == x.shape and y.dtype == dtype
+    if mask is not None:
+        assert "bias" in ops.last_attn_variant() or dtype == torch.float32, ops.last_attn_variant()
     if dtype == torch.float32:                                  # same inputs, same storage type as the reference run that made the golden
         assert rel_l2(to_np64(y), TEXT[case.name]) < TOL_F32
         assert worst(to_np64(y), TEXT[case.name]) < 1e-4
@@ -332,12 +335,121 @@ def test_text_processors_vs_reference_goldens(case, dtype):
     r = rounded(inp, dtype)
     w = O.AttnWeights(r["wq"], r["wk"], r["wv"], r["wo"], r["bo"], case.heads)
     if case.mode == "plain":
-        ref = O.plain_attention(r["x"], r.get("ctx"), w)
+        ref = O.plain_attention(r["x"], r.get("ctx"), w, mask=r.get("mask"))
     else:
         coef = torch.from_numpy(TEXT[case.name + "__coef"]).to(dtype).float().numpy()
         fn = O.outer_attention if case.mode.endswith("outer") else O.inner_attention
-        ref = fn(r["x"], r.get("ctx"), w, coef, case.mode.startswith("fused"))
+        ref = fn(r["x"], r.get("ctx"), w, coef, case.mode.startswith("fused"), mask=r.get("mask"))
     assert rel_l2(to_np64(y), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES + [torch.float32], ids=ids_dt)
+@pytest.mark.parametrize("d", [40, 64, 80, 160])
+def test_attention_core_with_score_bias(dtype, d):
+    """AidAttnArgs.bias (ABI v8) = diffusers' prepared attention_mask: every layout prepare_attention_mask / a caller can hand over
+    ([N * H, 1, L], [N, 1, L], [N, H, S, L], [N, S, L]), ragged L, several key tiles, PLAIN / pure INNER / pure OUTER, riders."""
+    n, s, l, h = 4, 70, 150, 2
+    q, k, v, vt = _core_inputs(n, s, l, h, d, dtype, seed=77 + d)
+    g = torch.Generator().manual_seed(d)
+    coef = torch.tensor([0.0, 0.35, 1.0, -1.0])                 # frame 3 = PLAIN rider
+    tol = 1e-5 if dtype == torch.float32 else TOL[dtype]
+
+    def additive(*shape):
+        keep = torch.rand(*shape, generator=g) > 0.4
+        keep[..., 0] = True
+        return ((1.0 - keep.float()) * -10000.0).to(dtype)
+    for shape in ((n * h, 1, l), (n, 1, l), (n, h, s, l), (n, s, l)):
+        m = additive(*shape)
+        m64 = to_np64(m)
+        for mode in ("plain", "inner", "outer"):
+            cf = coef if mode != "plain" else None
+            nr = 1 if mode != "plain" else 0
+            o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode=mode, fused=False, coef=None if cf is None else cf.to(DEV),
+                             begin=0, end=2, n_plain=nr, bias=m.to(DEV))
+            if mode == "plain":
+                ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, "plain", False, None, mask=m64)
+            else:                                               # frames 0 .. 2 interpolate between 0 and 2, frame 3 rides PLAIN
+                ref = np.empty((n, s, h * d))
+                mm = m64.reshape(n, -1, m64.shape[-2], l)
+                ref[:3] = O.attn_core(to_np64(q)[:3], to_np64(k)[:3], to_np64(v)[:3], h, d ** -0.5, mode, False, coef[:3].numpy(),
+                                      mask=mm[:3])
+                ref[3:] = O.attn_core(to_np64(q)[3:], to_np64(k)[3:], to_np64(v)[3:], h, d ** -0.5, "plain", False, None, mask=mm[3:])
+            err = rel_l2(to_np64(o), ref)
+            assert err < tol, (shape, mode, ops.last_attn_variant(), err)
+    # a strided view (every other query row of a larger mask) needs no copy
+    big = additive(n, 2 * s, l).to(DEV)
+    o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, bias=big[:, ::2])
+    ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, "plain", False, None, mask=to_np64(big[:, ::2])[:, None])
+    assert rel_l2(to_np64(o), ref) < tol
+    # masks written with -inf / finfo.min weigh their keys with exactly 0 (clamped to -1e30 inside the kernel)
+    for low in (float("-inf"), torch.finfo(dtype).min):
+        m = additive(n, 1, l)
+        m[m < 0] = low
+        o = ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, bias=m.to(DEV))
+        assert torch.isfinite(o).all()
+        m64 = np.where(to_np64(m) < 0, -1e30, 0.0)
+        ref = O.attn_core(to_np64(q), to_np64(k), to_np64(v), h, d ** -0.5, "plain", False, None, mask=m64[:, None])
+        assert rel_l2(to_np64(o), ref) < tol
+    # fused calls are refused by the library, like the reference's broadcast (aid_hip.h)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        ops.attn_fwd(q.to(DEV), k.to(DEV), vt.to(DEV), h, l=l, mode="outer", fused=True, coef=coef.to(DEV), end=2, n_plain=1,
+                     bias=additive(n, 1, l).to(DEV))
+
+
+def test_processor_attention_mask_protocol():
+    """What the boundary does with ``attention_mask`` (interpolation.py:604-606, 651-656, 738-739, 787): prepared by the attention
+    module, added to every segment's scores; fused processors fail like the reference (golden flag), IP processors too; the
+    de-activated processor hands it to its original_attn / runs PLAIN with it; a mask of zeros changes nothing."""
+    assert TEXT["fused_outer_with_mask_raises_runtime_error"][0] == 1 and TEXT["fused_inner_with_mask_raises_runtime_error"][0] == 1
+    dtype = torch.float16
+    case = next(c for c in C.TEXT_CASES if c.name == "mask_n3_d40_x_pure_outer")
+    inp = C.text_inputs(case)
+    attn = make_attn(aid_amd, inp, case.heads, case.cc, dtype, DEV)
+    x = torch.from_numpy(inp["x"]).to(dtype).to(DEV)
+    ctx = torch.from_numpy(inp["ctx"]).to(dtype).to(DEV)
+    mask = torch.from_numpy(inp["mask"]).to(dtype).to(DEV)
+    for cls in (aid_amd.OuterInterpolatedAttnProcessor, aid_amd.InnerInterpolatedAttnProcessor):
+        with pytest.raises(RuntimeError, match="must match the existing size"):
+            cls(t=0.3, is_fused=True)(attn, x, encoder_hidden_states=ctx, attention_mask=mask)
+        with pytest.raises(RuntimeError, match="float16 tensor"):
+            cls(t=0.3, is_fused=False)(attn, x, encoder_hidden_states=ctx, attention_mask=mask.float())
+        proc = cls(t=0.3, is_fused=False)
+        y0 = proc(attn, x, encoder_hidden_states=ctx)
+        assert rel_l2(to_np64(proc(attn, x, encoder_hidden_states=ctx, attention_mask=torch.zeros_like(mask))), to_np64(y0)) < 2e-3
+        # de-activated: the HIP plain processor takes the mask; the same numbers as HipAttnProcessor itself
+        proc.original_attn = aid_amd.HipAttnProcessor()
+        proc.deactivate()
+        assert torch.equal(proc(attn, x, encoder_hidden_states=ctx, attention_mask=mask),
+                           aid_amd.HipAttnProcessor()(attn, x, encoder_hidden_states=ctx, attention_mask=mask))
+    ipa = aid_amd.IPAdapterShim(case.c, case.cc, num_tokens=4, dtype=dtype, device=DEV)
+    ip = torch.randn(9, 1, 4, case.cc, dtype=dtype, device=DEV)
+    for cls in (aid_amd.OuterInterpolatedIPAttnProcessor, aid_amd.ScaleControlIPAttnProcessor):
+        with pytest.raises(RuntimeError, match="image-token scores"):
+            cls(t=0.3, is_fused=False, ip_attn=ipa)(attn, x, encoder_hidden_states=(ctx, [ip]), attention_mask=mask)
+
+
+@pytest.mark.parametrize("dtype", DTYPES + [torch.float32], ids=ids_dt)
+@pytest.mark.parametrize("name", ["n16_d64_s_fused_outer", "n16_d64_s_fused_inner", "n16_d64_x_fused_outer"])
+def test_shard_batches_of_the_16_frame_schedule_vs_reference_rows(name, dtype):
+    """BASELINE configs[3]: the 16-frame Beta(50, 50) sequence split over 8 / 4 / 2 ranks by dist.frame_shard.  A rank's batch
+    [frame 0 ; owned ; frame 15] with ITS rows of the coefficient schedule must reproduce the rows of the REFERENCE's 16-frame
+    output (every frame depends on itself and the two end points only) — the coefficient slicing pinned to reference output."""
+    from aid_amd import dist
+    case = next(c for c in C.TEXT_CASES if c.name == name)
+    inp = C.text_inputs(case)
+    attn = make_attn(aid_amd, inp, case.heads, case.cc if case.cross else None, dtype, DEV)
+    full = TEXT[name]
+    coef_full = torch.from_numpy(TEXT[name + "__coef"])
+    tol = TOL_F32 if dtype == torch.float32 else TOL[dtype]
+    for world in (8, 4, 2):
+        for rank in range(world):
+            rows = list(dist.frame_shard(case.n, world, rank).index)
+            proc = _text_proc(case)
+            proc.coef = coef_full[rows].clone()
+            x = torch.from_numpy(inp["x"][rows]).to(dtype).to(DEV)
+            ctx = torch.from_numpy(inp["ctx"][rows]).to(dtype).to(DEV) if case.cross else None
+            y = proc(attn, x, encoder_hidden_states=ctx)
+            assert rel_l2(to_np64(y), full[rows]) < tol, (world, rank, rows)
 
 
 @pytest.mark.parametrize("dtype", DTYPES + [torch.float32], ids=ids_dt)
@@ -388,7 +500,7 @@ def test_error_behaviour_batch_mismatch_dtype_and_mask():
         aid_amd.HipAttnProcessor()(attn, torch.randn(3, 16, 80, device=DEV))
     with pytest.raises(TypeError, match="float16 / bfloat16 storage"):   # the LayerNorm kernels are 16-bit only
         ops.layernorm(torch.randn(8, 64, device=DEV))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="float16 tensor"):            # a float32 mask against float16 scores (reference: baddbmm's dtype check)
         aid_amd.HipAttnProcessor()(attn, torch.randn(3, 16, 80, dtype=torch.float16, device=DEV),
                                    attention_mask=torch.zeros(3, 1, 16, device=DEV))
     attn_bad = aid_amd.AttnShim(96, 2, dtype=torch.float16, device=DEV)   # head dim 48 unsupported

@@ -16,7 +16,7 @@ class _Attn:                                # weakly referenceable stand-in for 
 
 
 def _fake_project(calls):
-    def project_kv(ctx, wk, wv, extra_rows=0, padded=False):
+    def project_kv(ctx, wk, wv, extra_rows=0):
         calls.append(tuple(ctx.shape))
         return ctx.clone(), ctx.clone()
     return project_kv
