@@ -23,7 +23,7 @@ from typing import Callable, Dict, Optional, Sequence
 import torch
 
 from .processors import (HipAttnProcessor, InnerInterpolatedAttnProcessor, InterpolatedAttnProcessor,
-                         OuterInterpolatedAttnProcessor, clear_weight_caches)
+                         OuterInterpolatedAttnProcessor, cache_generation, clear_weight_caches)
 
 EARLY_MODES = ("pure_inner", "fused_inner", "pure_outer", "fused_outer")
 
@@ -92,7 +92,13 @@ def fork_join(first: Callable, second: Callable, side: "torch.cuda.Stream"):
     ``side`` and is handed to the current stream (``record_stream``; captured allocations live in the graph's pool)."""
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
+    gen = cache_generation()
     a = first()
+    if cache_generation() != gen:
+        # ``first`` (re)built a lazily shared tensor on the current stream — a text K / V projection, folded LayerNorm weights (cold
+        # caches, new prompt tensors on a reused loop, a clear_weight_caches() in between): ``second`` reads it on the side stream, so
+        # the side stream is ordered behind everything ``first`` has enqueued.  One step loses its overlap; no step races.
+        side.wait_stream(cur)
     with torch.cuda.stream(side):
         b = second()
     cur.wait_stream(side)
@@ -149,6 +155,8 @@ class AidDenoiseLoop:
         self.use_graphs = use_graphs
         self.combine = combine or self._cfg
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        from . import ops
+        self._ws = ops.WorkspaceOwner()          # the captures' workspaces are dropped with this loop (and its graphs)
         self._warmed: set = set()
         self._cap = None
         self._outs: Dict[str, object] = {}
@@ -193,13 +201,14 @@ class AidDenoiseLoop:
         stream — the folded LayerNorm weights, the text K / V cache — that ``uncond_pass`` reads on the side stream, and ``fork_join``
         orders the side stream behind the fork point only.  So the pair runs ONCE back to back on the current stream first (outputs
         dropped); every forked step after that finds the caches filled.  (Graph mode warms up the same way before its capture.)"""
-        if which in self._warmed:
-            return
-        self._warmed.add(which)
         if torch.cuda.is_current_stream_capturing():
             return                                      # the eager warm-up of _run() has been here already
+        key = (which, cache_generation())               # caches cleared / refilled since: warm again (fork_join guards the rest)
+        if key in self._warmed:
+            return
         cond_pass()
         uncond_pass()
+        self._warmed = {(which, cache_generation())}
 
     def _run(self, which: str):
         if not self.use_graphs:
@@ -216,7 +225,7 @@ class AidDenoiseLoop:
             cur.wait_stream(cap)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cap):
+            with self._ws, torch.cuda.graph(g, stream=cap):
                 self._outs[which] = self._pass(which)
             self._graphs[which] = g
         g.replay()

@@ -10,6 +10,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import threading
+import weakref
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -97,15 +98,59 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 # ---- scratch memory --------------------------------------------------------------------------------------------------------
-# One workspace per (device, stream): kernels on one stream run in order, so reuse is safe.  Stream captures are special in two ways
-# (VERDICT r4 weak #11): (1) NOTHING is allocated inside a capture — the capture ADOPTS the workspace an eager call on the same stream
-# left behind (every capture in this package is preceded by an eager warm-up pass on the capture stream; a foreign capture without one
-# gets a RuntimeError that says so); (2) an adopted workspace belongs to that capture alone from then on — keyed by the capture's id
-# (aid_stream_capture_id), kept alive for the life of the process (the graph's kernels hold its address) and never handed to eager
-# calls or to another capture, even when torch recycles the stream handle.  ``release_workspaces()`` drops everything (only once
-# the graphs that were captured are gone).
+# One workspace per (device, stream): kernels on one stream run in order, so reuse is safe.  Stream captures get their OWN workspace,
+# keyed by the capture's id (aid_stream_capture_id) and never handed to eager calls or to another capture, even when torch recycles the
+# stream handle — a captured graph keeps the address for as long as it can be replayed.  Who keeps the memory alive:
+#   * captures of THIS package (``_PassGraphs``, ``AidDenoiseLoop``) run under a ``WorkspaceOwner``: the capture ADOPTS the workspace
+#     the eager warm-up on the capture stream left behind (nothing is allocated inside the capture), the owner records the key and
+#     drops it when the object that holds the graphs is released or garbage-collected (the adopted workspaces used to
+#     live for the life of the process, ~150 MB per captured SDXL pass kind);
+#   * a FOREIGN capture (``with torch.cuda.graph(g): unet(...)`` around processor calls) allocates its workspace inside the capture,
+#     i.e. from the graph's private pool: the memory belongs to the graph and goes when the graph goes.  The dictionary entry of a
+#     finished foreign capture is dropped at the next call on that stream.  (A capture torch's allocator does not know about
+#     cannot allocate: it adopts the workspace of an eager warm-up on the capture stream — kept for the life of the process — or
+#     gets a RuntimeError that asks for that warm-up.)
 _eager_ws: Dict[Tuple[int, int], torch.Tensor] = {}
 _capture_ws: Dict[Tuple[int, int, int], torch.Tensor] = {}
+_pool_keys: set = set()                      # keys of _capture_ws whose tensor lives in a foreign graph's private pool
+_ws_tls = threading.local()
+
+
+def _drop_capture_keys(keys: set) -> None:
+    for k in list(keys):
+        _capture_ws.pop(k, None)
+    keys.clear()
+
+
+class WorkspaceOwner:
+    """Ties the capture workspaces adopted inside ``with owner:`` blocks to the life of the object that holds the captured graphs:
+    ``release()`` — or the garbage collection of the owner — drops them.  Release only when the graphs are gone."""
+
+    def __init__(self):
+        self._keys: set = set()
+        self._fin = weakref.finalize(self, _drop_capture_keys, self._keys)
+
+    def __enter__(self):
+        stack = getattr(_ws_tls, "owners", None)
+        if stack is None:
+            stack = _ws_tls.owners = []
+        stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _ws_tls.owners.pop()
+        return False
+
+    def release(self) -> None:
+        _drop_capture_keys(self._keys)
+
+    def __len__(self) -> int:
+        return len(self._keys)
+
+
+def _current_owner() -> Optional[WorkspaceOwner]:
+    stack = getattr(_ws_tls, "owners", None)
+    return stack[-1] if stack else None
 
 
 def _capture_id(stream: int) -> int:
@@ -119,17 +164,36 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     dev = device.index if device.index is not None else torch.cuda.current_device()
     stream = _stream()
     cid = _capture_id(stream) if torch.cuda.is_current_stream_capturing() else 0
+    for k in [k for k in _pool_keys if k[0] == dev and k[1] == stream and k[2] != cid]:
+        _pool_keys.discard(k)                                   # a foreign capture on this stream has ended: its pool owns the memory
+        _capture_ws.pop(k, None)
     if cid:
-        ws = _capture_ws.get((dev, stream, cid))
+        key = (dev, stream, cid)
+        ws = _capture_ws.get(key)
+        if ws is not None and ws.numel() >= nbytes:
+            return ws
+        owner = _current_owner()
+        if owner is None and (ws is None or key in _pool_keys):  # foreign capture: the graph's private pool owns its workspace
+            # (a later, larger request of the same capture allocates again; the smaller block goes back to that pool, stream-ordered)
+            try:
+                ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+                _capture_ws[key] = ws
+                _pool_keys.add(key)
+                return ws
+            except RuntimeError:                                # a capture torch's allocator does not know about
+                ws = None
         if ws is None:
             ws = _eager_ws.pop((dev, stream), None)             # adopt: eager calls on this stream allocate afresh from now on
             if ws is not None:
-                _capture_ws[(dev, stream, cid)] = ws
+                _capture_ws[key] = ws
+                if owner is not None:
+                    owner._keys.add(key)
         if ws is None or ws.numel() < nbytes:
             raise RuntimeError(
                 f"a library call inside a stream capture needs {nbytes} bytes of workspace on a stream that has "
                 f"{'none' if ws is None else str(ws.numel()) + ' bytes'}: run the same calls once EAGERLY on the capture stream first "
-                "(torch.cuda.graph(g, stream=s) after a warm-up under torch.cuda.stream(s)) — nothing is allocated inside a capture")
+                "(torch.cuda.graph(g, stream=s) after a warm-up under torch.cuda.stream(s)) — the capture then adopts the warm-up's "
+                "workspace")
         return ws
     key = (dev, stream)
     ws = _eager_ws.get(key)
@@ -143,6 +207,7 @@ def release_workspaces() -> None:
     """Drop every cached workspace (also the ones captured graphs still point into: call it when those graphs are gone)."""
     _eager_ws.clear()
     _capture_ws.clear()
+    _pool_keys.clear()
 
 
 # ---- per-call hint: launch streams that share the device ---------------------------------------------------------------------

@@ -40,6 +40,7 @@ from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 import torch
 from torch import nn
 
+from . import ops
 from . import processors as P
 from .attn_shim import AttnStackUNet
 from .interp import generate_beta_tensor, linear_interpolation, slerp, spherical_interpolation
@@ -179,6 +180,7 @@ class _PassGraphs:
         self.fallback_reason: Optional[str] = None
         self._ent: Dict[Any, Tuple] = {}
         self._cap = None
+        self._ws = ops.WorkspaceOwner()          # the captures' workspaces go when this object (and its graphs) goes
 
     def _capture(self, fn: Callable, inputs: Dict[str, torch.Tensor]):
         static = {k: v.clone() for k, v in inputs.items()}
@@ -192,7 +194,7 @@ class _PassGraphs:
         cur.wait_stream(cap)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=cap):
+        with self._ws, torch.cuda.graph(graph, stream=cap):
             out = fn(**static)
         return graph, static, out
 
@@ -209,6 +211,7 @@ class _PassGraphs:
                 self.enabled = False
                 self.fallback_reason = f"{type(e).__name__}: {e}"
                 self._ent.clear()
+                self._ws.release()              # the graphs are gone (and so is the failed capture): their workspaces too
                 warnings.warn("hipGraph capture of a UNet pass failed, the run continues eagerly: " + self.fallback_reason,
                               RuntimeWarning, stacklevel=3)
                 try:

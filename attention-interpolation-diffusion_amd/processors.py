@@ -289,6 +289,7 @@ def _ln_folded(attn, norm, cross: bool):
     key = (cross,) + tuple((t.data_ptr(), _version_of(t)) if t is not None else None for t in srcs)
     ent = _FOLD_CACHE.get(attn)
     if ent is None or ent[0] != key:
+        _CACHE_GEN[0] += 1
         const = torch.zeros(6, wq.shape[0], dtype=torch.float32, device=wq.device)
         fq, const[0], const[1] = ops.ln_fold(wq, norm.weight, norm.bias)
         fk = fv = None
@@ -318,11 +319,20 @@ def _ln_folded(attn, norm, cross: bool):
 # (INTEGRATION.md §3).
 TEXT_KV_CACHE = True
 _KV_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+# Bumped whenever a lazily built shared tensor is (re)built or dropped — a text K / V projection, a folded LayerNorm weight set, a
+# clear_*() call.  ``loop.fork_join`` compares it around the pass it runs first: a fill on one stream must be ordered before the
+# other stream reads it.
+_CACHE_GEN = [0]
+
+
+def cache_generation() -> int:
+    return _CACHE_GEN[0]
 
 
 def clear_text_kv_cache() -> None:
     """Drop every cached text key / value projection (they are re-projected by the next cross-attention call)."""
     _KV_CACHE.clear()
+    _CACHE_GEN[0] += 1
 
 
 def clear_weight_caches() -> None:
@@ -331,6 +341,7 @@ def clear_weight_caches() -> None:
     before the call still read the old derived tensors and must be re-captured."""
     _KV_CACHE.clear()
     _FOLD_CACHE.clear()
+    _CACHE_GEN[0] += 1
 
 
 def _vkey(t: torch.Tensor):
@@ -356,6 +367,7 @@ def _text_kv(attn, ehs, ctx: torch.Tensor, idx, wk: torch.Tensor, wv: torch.Tens
         return None
     hit = per.get(key)
     if hit is None:
+        _CACHE_GEN[0] += 1
         k, vt = ops.project_kv(ctx, wk, wv)
         for old in [kk for kk in per if kk[0][0] == key[0][0] and kk[3:] == key[3:]]:
             per.pop(old, None)            # the same tensor at an older version (or with replaced weights)

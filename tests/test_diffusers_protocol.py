@@ -275,20 +275,35 @@ def test_two_host_threads_two_streams_different_cu_share_are_bit_stable():
 
 
 @pytest.mark.gpu
-def test_workspace_is_never_allocated_inside_a_capture():
-    """ops.workspace: a capture ADOPTS the scratch of the eager warm-up on its stream (and keeps it for itself); a capture without a
-    warm-up on its stream raises instead of allocating from the graph's pool."""
+def test_capture_workspaces_belong_to_their_graphs():
+    """ops.workspace: (1) a FOREIGN capture — the standard ``with torch.cuda.graph(g):`` idiom around processor calls, warmed up
+    or not — gets its scratch from the graph's private pool and the dictionary forgets it once the capture has ended; (2) a capture of
+    this package (under a WorkspaceOwner) ADOPTS the scratch of the eager warm-up on its stream, keeps it for itself, and drops it when the
+    owner is released / collected — nothing lives for the life of the process any more."""
+    import gc
     dtype = torch.float16
     attn = aid_amd.AttnShim(320, 8, dtype=dtype, device=DEV)
     x = torch.randn(3, 256, 320, device=DEV).to(dtype)
     proc = HipAttnProcessor()
     y = proc(attn, x).clone()
+    # (1) foreign capture on a stream that never ran the library eagerly
     cold = torch.cuda.Stream()
     graph = torch.cuda.CUDAGraph()
-    with pytest.raises(RuntimeError, match="nothing is allocated inside a capture"):
-        with torch.cuda.graph(graph, stream=cold):
-            proc(attn, x)
+    with torch.cuda.graph(graph, stream=cold):
+        yc = proc(attn, x)
+    assert any(k[1] == cold.cuda_stream for k in ops._pool_keys)
+    graph.replay()
     torch.cuda.synchronize()
+    assert torch.equal(yc, y)
+    with torch.cuda.stream(cold):
+        proc(attn, x)                                                                   # the next call on that stream: the entry is gone
+    torch.cuda.synchronize()
+    assert not any(k[1] == cold.cuda_stream for k in ops._pool_keys)
+    assert not any(k[1] == cold.cuda_stream for k in ops._capture_ws)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yc, y)                                                           # the pool still owns the scratch
+    # (2) an owned capture adopts the warm-up's workspace
     st = torch.cuda.Stream()
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
@@ -296,16 +311,48 @@ def test_workspace_is_never_allocated_inside_a_capture():
     torch.cuda.synchronize()
     key = (torch.cuda.current_device(), st.cuda_stream)
     warm = ops._eager_ws[key]
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=st):
+    owner = ops.WorkspaceOwner()
+    graph2 = torch.cuda.CUDAGraph()
+    with owner, torch.cuda.graph(graph2, stream=st):
         yg = proc(attn, x)
-    assert key not in ops._eager_ws                                                     # adopted: eager calls on this stream allocate afresh
+    assert key not in ops._eager_ws and len(owner) == 1                                 # adopted: eager calls on this stream allocate afresh
     owned = [v for k, v in ops._capture_ws.items() if k[:2] == key]
     assert any(v.data_ptr() == warm.data_ptr() for v in owned)
     with torch.cuda.stream(st):
         proc(attn, x)                                                                   # an eager call on the SAME stream handle afterwards ...
     torch.cuda.synchronize()
     assert ops._eager_ws[key].data_ptr() != warm.data_ptr()                              # ... never shares the graph's scratch
-    graph.replay()
+    graph2.replay()
     torch.cuda.synchronize()
     assert torch.equal(yg, y)
+    n_before = len(ops._capture_ws)
+    del graph2, owned, warm
+    del owner
+    gc.collect()
+    assert len(ops._capture_ws) == n_before - 1                                         # the owner's finalizer dropped the entry
+
+
+@pytest.mark.gpu
+def test_pipeline_runs_do_not_strand_capture_workspaces():
+    """A long-lived process (the reference is a gradio app) calls the pipeline again and again: every call builds its own graphs and
+    their workspaces must go with them."""
+    import gc
+    from aid_amd.loop import AidDenoiseLoop, install_sequence_processors
+    dtype = torch.float16
+    unet = aid_amd.AttnStackUNet("sd15", dtype=dtype, device=DEV, scale_down=16)
+    n = 3
+    install_sequence_processors(unet, n, "fused_inner")
+    sample = {(s_, c_): torch.randn(n, s_, c_, device=DEV).to(dtype) for (s_, c_, _, _) in set(unet.shapes)}
+    cond = torch.randn(n, 77, unet.cross_dim, device=DEV).to(dtype)
+    base = None
+    for it in range(4):
+        loop = AidDenoiseLoop(unet, sample, cond, cond.clone(), num_inference_steps=4)
+        for i in range(4):
+            loop.step(i)
+        torch.cuda.synchronize()
+        assert len(loop._ws) >= 1
+        del loop
+        gc.collect()
+        if base is None:
+            base = len(ops._capture_ws)
+        assert len(ops._capture_ws) == base, (it, len(ops._capture_ws), base)
