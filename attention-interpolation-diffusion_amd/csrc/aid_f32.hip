@@ -28,13 +28,20 @@ __device__ __forceinline__ f32x16 mfma32f(float a, float b, const f32x16& c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// GEMM
+// GEMM: 128 x 128 x 16 tiles, four waves of 64 x 64 (2 x 2 blocks of 32 x 32), global -> registers -> LDS with the next K tile's
+// loads in flight during the current tile's MFMAs (two LDS buffers, one barrier per K tile).
+//   * `v_mfma_f32_32x32x2_f32` contracts TWO k per instruction: the lower lane half supplies one, the upper half the other.  Any
+//     pairing of k values works as long as both operands use the same one, so inside a group of 8 consecutive k the lower half takes
+//     k = 0 .. 3 and the upper half k = 4 .. 7: ONE 16-byte LDS read per lane then feeds FOUR MFMAs (the first version read one
+//     float per MFMA: 27 TFLOP/s of the 157 peak).
+//   * LDS rows of 16 + 4 floats: row r of a tile starts at bank 20 r mod 64 — 16 distinct multiples of 4 over the 16 rows of a
+//     `ds_read_b128` lane group, and over the 2 x 4 (row, quad) lanes of a `ds_write_b128` group: no conflicts either way.
+//   * the swapped product D[n][m] leaves four consecutive n of one row m in a lane: 16-byte stores where the options allow.
 // ------------------------------------------------------------------------------------------------
-constexpr int FBM = 64, FBN = 64, FBK = 16, FLD = FBK + 1;       // padded LDS rows: (17 r + k) mod 32 is conflict-free over r
+constexpr int FBM = 128, FBN = 128, FBK = 16, FLD = FBK + 4;
 
 __global__ __launch_bounds__(256) void aid_gemm_f32_kernel(const GemmGroup g) {
-    __shared__ float As[FBM * FLD];
-    __shared__ float Bs[FBN * FLD];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (FBM + FBN) * FLD];
     // ---- block -> (problem, batch, tile)
     int p = 0;
 #pragma unroll
@@ -45,6 +52,7 @@ __global__ __launch_bounds__(256) void aid_gemm_f32_kernel(const GemmGroup g) {
     const int tiles_n = (P.n + FBN - 1) / FBN, tiles_m = (P.m + FBM - 1) / FBM;
     const int batch = rem / (tiles_m * tiles_n);
     rem -= batch * tiles_m * tiles_n;
+    // column tiles of one row panel are neighbours in the grid: they share the A panel in L2
     const int m0 = (rem / tiles_n) * FBM, n0 = (rem % tiles_n) * FBN;
     const float* __restrict__ A = reinterpret_cast<const float*>(P.a) + (int64_t)batch * P.stride_a;
     const float* __restrict__ B = reinterpret_cast<const float*>(P.b) + (int64_t)batch * P.stride_b;
@@ -52,61 +60,116 @@ __global__ __launch_bounds__(256) void aid_gemm_f32_kernel(const GemmGroup g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    const int srow = tid >> 2, sk = (tid & 3) * 4;                 // staging: 64 rows x 4 quads of k
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    // staging: thread -> (row = tid / 4 [+ 64], k quad = tid % 4); rows past the matrix are clamped (their products are never stored)
+    const int srow = tid >> 2, sq = (tid & 3) * 4;
+    const float* a0 = A + (int64_t)min(m0 + srow, P.m - 1) * P.lda + sq;
+    const float* a1 = A + (int64_t)min(m0 + srow + 64, P.m - 1) * P.lda + sq;
+    const float* b0 = B + (int64_t)min(n0 + srow, P.n - 1) * P.ldb + sq;
+    const float* b1 = B + (int64_t)min(n0 + srow + 64, P.n - 1) * P.ldb + sq;
 
-    f32x16 acc;
+    f32x16 acc[2][2];                                      // [n block][m block]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int k0 = 0; k0 < P.k; k0 += FBK) {
-        float ra[4], rb[4];
+    f32x4 ra[2], rb[2];
+    auto load = [&](int k0) {                              // k is a multiple of 8 (aid_hip.h): a quad is inside the row or past it
+        const bool in = k0 + sq < P.k;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ra[0] = in ? *reinterpret_cast<const f32x4*>(a0 + k0) : z;
+        ra[1] = in ? *reinterpret_cast<const f32x4*>(a1 + k0) : z;
+        rb[0] = in ? *reinterpret_cast<const f32x4*>(b0 + k0) : z;
+        rb[1] = in ? *reinterpret_cast<const f32x4*>(b1 + k0) : z;
+    };
+    auto store = [&](int buf) {
+        float* As = smem + buf * (FBM + FBN) * FLD;
+        float* Bs = As + FBM * FLD;
+        *reinterpret_cast<f32x4*>(As + srow * FLD + sq) = ra[0];
+        *reinterpret_cast<f32x4*>(As + (srow + 64) * FLD + sq) = ra[1];
+        *reinterpret_cast<f32x4*>(Bs + srow * FLD + sq) = rb[0];
+        *reinterpret_cast<f32x4*>(Bs + (srow + 64) * FLD + sq) = rb[1];
+    };
+
+    const int nk = (P.k + FBK - 1) / FBK;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) load((t + 1) * FBK);
+        const float* As = smem + (t & 1) * (FBM + FBN) * FLD;
+        const float* Bs = As + FBM * FLD;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int kk = k0 + sk + e;
-            ra[e] = (m0 + srow < P.m && kk < P.k) ? A[(int64_t)(m0 + srow) * P.lda + kk] : 0.f;
-            rb[e] = (n0 + srow < P.n && kk < P.k) ? B[(int64_t)(n0 + srow) * P.ldb + kk] : 0.f;
-        }
-        __syncthreads();                                           // the previous tile has been consumed
+        for (int kg = 0; kg < 2; ++kg) {                   // two groups of 8 k per tile
+            f32x4 fa[2], fb[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            As[srow * FLD + sk + e] = ra[e];
-            Bs[srow * FLD + sk + e] = rb[e];
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const f32x4*>(As + (wm + 32 * i + l31) * FLD + 8 * kg + 4 * hi);
+                fb[i] = *reinterpret_cast<const f32x4*>(Bs + (wn + 32 * i + l31) * FLD + 8 * kg + 4 * hi);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)            // D[n][m]: lane (m = l31, hi) ends up with n = 8 g + 4 hi + e
+                        acc[i][j] = mfma32f(fb[i][e], fa[j][e], acc[i][j]);
         }
+        if (t + 1 < nk) store((t + 1) & 1);
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < FBK; kk += 2)                        // D[n][m]: lane (m = l31, hi) ends up with n = 8 g + 4 hi + e
-            acc = mfma32f(Bs[(wn + l31) * FLD + kk + hi], As[(wm + l31) * FLD + kk + hi], acc);
     }
 
     // ---- epilogue (every option of AidGemmProblem; fp32 needs no intermediate rounding)
-    const int m = m0 + wm + l31;
-    if (m >= P.m) return;
     const float* stats = P.ln_stats ? P.ln_stats + 2 * (int64_t)batch * P.stride_stats : nullptr;
     const float* bias = reinterpret_cast<const float*>(P.bias);
     const float* R = reinterpret_cast<const float*>(P.residual);
+    const bool vec = !P.trans_rows && !stats && P.n % 4 == 0 &&     // whole 16-byte groups of a row: one store each
+                     (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0;
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq)
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm + 32 * j + l31;
+        if (m >= P.m) continue;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int n = n0 + wn + 8 * gq + 4 * hi + e;
-            if (n >= P.n) {                                        // columns [n, round_up(n, 4)) are written with zeros (aid_hip.h)
-                if (!P.trans_rows && n < (P.n + 3) / 4 * 4) C[(int64_t)m * P.ldc + n] = 0.f;
-                continue;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int nb = n0 + wn + 32 * i + 8 * gq + 4 * hi;
+                if (vec) {
+                    if (nb >= P.n) continue;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e] * P.scale;
+                    if (bias) v += *reinterpret_cast<const f32x4*>(bias + nb);
+                    const int64_t off = (int64_t)m * P.ldc + nb;
+                    if (R) v += *reinterpret_cast<const f32x4*>(R + off);
+                    *reinterpret_cast<f32x4*>(C + off) = v;
+                    continue;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = nb + e;
+                    if (n >= P.n) {                                // columns [n, round_up(n, 4)) are written with zeros (aid_hip.h)
+                        if (!P.trans_rows && n < (P.n + 3) / 4 * 4) C[(int64_t)m * P.ldc + n] = 0.f;
+                        continue;
+                    }
+                    float v = acc[i][j][4 * gq + e];
+                    if (stats) {                                   // folded LayerNorm: rstd (x W'^T - mean colsum) + shift
+                        if (P.ln_side == 1) v = fmaf(stats[2 * m + 1], fmaf(-stats[2 * m], P.ln_colsum[n], v), P.ln_shift[n]);
+                        else                v = fmaf(stats[2 * n + 1], fmaf(-stats[2 * n], P.ln_colsum[m], v), P.ln_shift[m]);
+                    }
+                    v *= P.scale;
+                    if (bias) v += bias[n];
+                    int64_t off;
+                    if (P.trans_rows) off = (int64_t)(m / P.trans_rows) * P.stride_c + (int64_t)n * P.ldc + m % P.trans_rows;
+                    else              off = (int64_t)m * P.ldc + n;
+                    if (R) v += R[off];
+                    C[off] = v;
+                }
             }
-            float v = acc[4 * gq + e];
-            if (stats) {                                           // folded LayerNorm: rstd (x W'^T - mean colsum) + shift
-                if (P.ln_side == 1) v = fmaf(stats[2 * m + 1], fmaf(-stats[2 * m], P.ln_colsum[n], v), P.ln_shift[n]);
-                else                v = fmaf(stats[2 * n + 1], fmaf(-stats[2 * n], P.ln_colsum[m], v), P.ln_shift[m]);
-            }
-            v *= P.scale;
-            if (bias) v += bias[n];
-            int64_t off;
-            if (P.trans_rows) off = (int64_t)(m / P.trans_rows) * P.stride_c + (int64_t)n * P.ldc + m % P.trans_rows;
-            else              off = (int64_t)m * P.ldc + n;
-            if (R) v += R[off];
-            C[off] = v;
-        }
+    }
 }
 
 hipError_t gemm_f32_launch(GemmGroup& g, hipStream_t stream) {
@@ -137,10 +200,13 @@ __device__ __forceinline__ int key_of(int r, int hi) { return (r & 3) + 8 * (r >
 template <int D>
 __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p) {
     constexpr int DP = (D + 31) / 32 * 32, NDB = DP / 32;          // channels padded to whole 32-blocks of the PV product
-    constexpr int KLD = D + 1;                                     // K tile rows [32][D + 1]
-    constexpr int VLD = FKT + 1;                                   // V^T tile rows [DP][33]
-    __shared__ float Ks[FKT * KLD];
-    __shared__ float Vs[DP * VLD];
+    // LDS rows of D + 4 / 32 + 4 floats: (row stride / 4) is odd, so the 16 rows of a `ds_read_b128` lane group start at 16 distinct
+    // multiples of four banks — every fragment read below is one conflict-free 16-byte read that feeds FOUR MFMAs (see the GEMM).
+    constexpr int KLD = D + 4;                                     // K tile rows [32][D + 4]
+    constexpr int VLD = FKT + 4;                                   // V^T tile rows [DP][36]
+    static_assert((KLD / 4) % 2 == 1 && (VLD / 4) % 2 == 1 && D % 8 == 0, "conflict-free 16-byte fragment reads");
+    __shared__ __attribute__((aligned(16))) float Ks[FKT * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[DP * VLD];
     const AidAttnArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -153,9 +219,15 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
     const bool qok = q < a.s;
 
     const float* __restrict__ Q = reinterpret_cast<const float*>(a.q) + (int64_t)fr * a.q_fs + (int64_t)min(q, a.s - 1) * a.ldq + h * D;
-    float qf[D / 2];                                               // Q[q][2 t + hi], pre-multiplied by softmax_scale log2(e)
+    // Q[q][8 g + 4 hi + e] at qf[4 g + e], pre-multiplied by softmax_scale log2(e): inside a group of 8 channels the lower lane half
+    // contracts channels 0 .. 3 and the upper half 4 .. 7 (the K fragment reads below use the same pairing)
+    float qf[D / 2];
 #pragma unroll
-    for (int t = 0; t < D / 2; ++t) qf[t] = Q[2 * t + hi] * p.c2;
+    for (int gq = 0; gq < D / 8; ++gq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Q + 8 * gq + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qf[4 * gq + e] = v[e] * p.c2;
+    }
 
     // ---- what this frame attends with (decided per frame from the coefficient, like aid_attn_kernel)
     const float cf = (a.mode != AID_MODE_PLAIN && a.coef) ? a.coef[fr] : -1.f;
@@ -189,13 +261,24 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
             if (!kp) continue;
             for (int t0 = 0; t0 < a.l; t0 += FKT) {
                 __syncthreads();                                   // the previous tile has been consumed by every wave
-                for (int i = tid; i < FKT * D; i += 256) {         // K tile [key][channel]
-                    const int kk = i / D, c = i - kk * D;
-                    Ks[kk * KLD + c] = (t0 + kk < a.l) ? kp[(int64_t)(t0 + kk) * a.ldk + h * D + c] : 0.f;
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                for (int i = tid; i < FKT * (D / 4); i += 256) {   // K tile [key][channel], 16 bytes at a time
+                    const int kk = i / (D / 4), c = (i - kk * (D / 4)) * 4;
+                    *reinterpret_cast<f32x4*>(Ks + kk * KLD + c) =
+                        (t0 + kk < a.l) ? *reinterpret_cast<const f32x4*>(kp + (int64_t)(t0 + kk) * a.ldk + h * D + c) : z4;
                 }
-                for (int i = tid; i < DP * FKT; i += 256) {        // V^T tile [channel][key]
-                    const int c = i / FKT, kk = i - c * FKT;
-                    Vs[c * VLD + kk] = (c < D && t0 + kk < a.l) ? vp[(int64_t)(h * D + c) * a.ldvt + t0 + kk] : 0.f;
+                for (int i = tid; i < DP * (FKT / 4); i += 256) {  // V^T tile [channel][key]; keys past L and pad channels are zero
+                    const int c = i / (FKT / 4), kk = (i - c * (FKT / 4)) * 4;
+                    f32x4 v = z4;
+                    if (c < D && t0 + kk < a.l) {
+                        const float* src = vp + (int64_t)(h * D + c) * a.ldvt + t0 + kk;
+                        if (t0 + kk + 3 < a.l) v = *reinterpret_cast<const f32x4*>(src);   // (ldvt, t0 and kk are multiples of 4)
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (t0 + kk + e < a.l) ? src[e] : 0.f;
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(Vs + c * VLD + kk) = v;
                 }
                 __syncthreads();
                 // S^T = K Q'^T: lane (query l31, half hi) receives the scores of keys key_of(r, hi)
@@ -203,7 +286,11 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
-                for (int t = 0; t < D / 2; ++t) sc = mfma32f(Ks[l31 * KLD + 2 * t + hi], qf[t], sc);
+                for (int gq = 0; gq < D / 8; ++gq) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + l31 * KLD + 8 * gq + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sc = mfma32f(kf[e], qf[4 * gq + e], sc);
+                }
                 if (brow) {                                        // scale q k^T + bias, in the log2 domain (values below -1e30 clamped, aid_attn.hip)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -226,14 +313,20 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
                     ps += sc[r];
                 }
                 lsum = lsum * alpha + ps;
-                // O^T = alpha O^T + V^T P^T: k-step r contracts keys key_of(r, 0) (lower lane half) and key_of(r, 1) (upper)
+                // O^T = alpha O^T + V^T P^T: k-step r contracts keys key_of(r, 0) (lower lane half) and key_of(r, 1) (upper);
+                // registers 4 j .. 4 j + 3 of a lane are the four CONSECUTIVE keys 8 j + 4 hi + {0 .. 3}: one 16-byte read of the V^T row
 #pragma unroll
-                for (int d = 0; d < NDB; ++d) {
+                for (int d = 0; d < NDB; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d] = mfma32f(Vs[(32 * d + l31) * VLD + key_of(r, hi)], sc[r], o[d]);
-                }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) {                // (block-inner: consecutive MFMAs go to different accumulators)
+                        const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + (32 * d + l31) * VLD + 8 * j + 4 * hi);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[d] = mfma32f(vf[e], sc[4 * j + e], o[d]);
+                    }
             }
         }
         const float inv = w / sum_halves(lsum);

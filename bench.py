@@ -135,16 +135,18 @@ def make_inputs(unet, n_frames, dtype, device, seed=1002, n_ctx=None):
 
 
 def recorded_traffic(stack, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC collection (profiles/r04_pmc.json, written by
-    tools/pmc_collect.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, gfx950 x2
-    correction on FETCH_SIZE applied).  PMC counters cannot be collected from inside this process; null if absent."""
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
+    """(HBM bytes per launch of `kernel`, where the number comes from).  PMC counters cannot be collected from inside this process:
+    the figure is READ from the newest committed PMC collection that has the kernel (profiles/rNN_pmc.json, written by
+    tools/pmc_collect.py on the builder's GPU box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command,
+    gfx950 x2 correction on FETCH_SIZE applied) — it is NOT a measurement of the run that prints it; (None, None) if absent."""
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["models"][stack][kernel]["hbm_bytes_per_launch"]
+                return (json.load(f)["models"][stack][kernel]["hbm_bytes_per_launch"],
+                        f"profiles/{name} (builder's box, rocprofv3 --pmc over this command; not measured by this run)")
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def parity_statement(dt):
@@ -205,10 +207,11 @@ def roofline_object(agg, stack):
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     ach_x = d["flops_executed"] / (d["ms"] * 1e-3) / 1e12
     tot_ms = sum(v["ms"] for v in agg.values())
+    traffic, traffic_source = recorded_traffic(stack, dom)
     return {
         "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
         "achieved_executed": ach_x, "frac_executed": ach_x / MFMA_PEAK_TFLOPS,
-        "traffic": recorded_traffic(stack, dom), "kernel": dom, "launches": d["launches"],
+        "traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "launches": d["launches"],
         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
         "avg_launch_us": d["ms"] * 1e3 / d["launches"], "avg_launch_gflop": d["flops"] / d["launches"] / 1e9,
         "avg_launch_gflop_executed": d["flops_executed"] / d["launches"] / 1e9,
@@ -259,6 +262,7 @@ def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
     for loc, nblk, s, c, h in spec["layers"]:
         levels[(s, c, h)] = levels.get((s, c, h), 0) + nblk
     t_aid = t_plain = 0.0
+    lo_aid = lo_plain = hi_aid = hi_plain = 0.0           # the same sums from the fastest / the slowest run of every call
     t0_all = time.time()
     detail, scaled = [], []
 
@@ -282,7 +286,7 @@ def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
         ws = (rn(c, c, sc=c ** -0.5), rn(c, c, sc=c ** -0.5), rn(c, c, sc=c ** -0.5), rn(c, c, sc=c ** -0.5), rn(c, sc=.01))
         wx = (ws[0], rn(c, cc, sc=cc ** -0.5), rn(c, cc, sc=cc ** -0.5), ws[3], ws[4])
         single = s > 1024
-        med = {}
+        med, lo, hi = {}, {}, {}
         for tag, xx, cx, w, md, fu, cf in (("aid_self", x, None, ws, mode, fused, coef), ("aid_cross", x, ctx, wx, mode, fused, coef),
                                            ("plain_self", x, None, ws, "plain", False, None),
                                            ("plain_cross", x, ctx, wx, "plain", False, None)):
@@ -291,17 +295,29 @@ def cpu_baseline(stack, n_frames, early, steps, warmup_ratio, budget_s=25.0):
                 fa = 8.0 * 3 * s * c * c + 4.0 * 3 * s * s * c * segs
                 fp = 8.0 * 3 * s * c * c + 4.0 * 3 * s * s * c
                 med[tag] = med["aid_self"] * fp / fa
+                lo[tag], hi[tag] = lo["aid_self"] * fp / fa, hi["aid_self"] * fp / fa
                 scaled.append(f"S={s} plain self call = AID self call x {fp / fa:.2f} (flop ratio)")
                 continue
             ts = timed(xx, cx, w, h, md, fu, cf, single)
             med[tag] = statistics.median(ts)
+            lo[tag], hi[tag] = ts[0], ts[-1]
             detail.append(f"S={s} C={c} {tag}: " + "/".join(f"{t:.2f}" for t in (ts[0], med[tag], ts[-1])) + " s")
         t_aid += nblk * (med["aid_self"] + med["aid_cross"]) * n_frames / 3.0
         t_plain += nblk * (med["plain_self"] + med["plain_cross"]) * n_frames / 3.0
+        lo_aid += nblk * (lo["aid_self"] + lo["aid_cross"]) * n_frames / 3.0
+        lo_plain += nblk * (lo["plain_self"] + lo["plain_cross"]) * n_frames / 3.0
+        hi_aid += nblk * (hi["aid_self"] + hi["aid_cross"]) * n_frames / 3.0
+        hi_plain += nblk * (hi["plain_self"] + hi["plain_cross"]) * n_frames / 3.0
     n_aid = int(steps * warmup_ratio)
-    total = n_aid * (t_aid + t_plain) + (steps - n_aid) * 2 * t_plain
-    return dict(value=n_frames / (total * 50.0 / steps), unit="interpolation-frames/sec (50-step)",
+    tot = lambda a, p_: n_aid * (a + p_) + (steps - n_aid) * 2 * p_      # noqa: E731
+    total = tot(t_aid, t_plain)
+    val = lambda t_: n_frames / (t_ * 50.0 / steps)                       # noqa: E731
+    return dict(value=val(total), unit="interpolation-frames/sec (50-step)",
                 cores=torch.get_num_threads(), kind="port",
+                # how far the extrapolation moves with the run-to-run noise of the sampled calls (rounds 2 - 5 printed 0.00088 - 0.0018
+                # for this workload): the value from every call's slowest / fastest run; the S = 4096 calls are single shots (lo = hi)
+                spread={"value_low": val(tot(hi_aid, hi_plain)), "value_high": val(tot(lo_aid, lo_plain)),
+                        "note": "same extrapolation from the slowest / the fastest run of every sampled call; a baseline, not a target"},
                 sample=(f"oracle/aid_cpu_port.py (torch CPU ops, fp32, torch.get_num_threads() = {torch.get_num_threads()} = the cpus this "
                         f"process may use, of {cores} host cpus): 1 transformer block (self + cross call) per resolution level in {early} and in "
                         f"plain mode on the 3-frame sub-batch [first, middle, last]; every call in full (all heads, all rows, real S): S <= 1024 one "
@@ -520,6 +536,13 @@ def main():
         result["config"]["ip_adapter"] = (f"{args.ip_tokens} image tokens per frame, image embeddings [3 N, 1, T, Cc]; AID pass = "
                                           f"{wl['early']} IP processors, other passes = IP-Adapter attention (text + scale x image)")
     if world > 1:
+        # every rank contributes (rank, device index) through the job's own collective backend: the driver can check that N distinct
+        # ranks on N distinct devices took part
+        mine = torch.tensor([rank, dev_index], device="cpu" if one_dev else device, dtype=torch.int64)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        result["rccl_ranks_seen"] = sorted(int(t[0]) for t in seen)
+        result["devices_seen"] = sorted(int(t[1]) for t in seen)
         mk = adist.owned_shard if args.endpoints == "exchange" else adist.frame_shard
         mlb = max(mk(wl["n_total"], world, r).n_local for r in range(world))
         result["config"]["max_local_batch"] = mlb
@@ -591,6 +614,17 @@ def main():
             result["also"]["sdxl_sublayers_fused"] = {"value": t7["value"], "unit": "frames/s", "ms_per_step": t7["ms_per_step"],
                                                       "repeats": t7["repeats"], "dtype": w7["dtype"],
                                                       "sublayers": "h += attn(LayerNorm(h), ctx) per layer in one library call, residual stream chained"}
+            # the same workload as a second TOP-LEVEL object with its own per-kernel roofline: the number a real
+            # UNet is closer to — every layer reads what the previous one wrote, LayerNorm statistics and the residual add included
+            chained = dict(result["also"]["sdxl_sublayers_fused"], metric=result["metric"],
+                           workload=w7["what"] + "; every attention call as h += attn(LayerNorm(h), ctx), the residual stream of a "
+                                                  "resolution level chained through its layers")
+            if not args.no_roofline:
+                r7 = roofline_object(roofline_pass(w7["loop"], aid_amd, torch), "sdxl")
+                chained["roofline"] = {k: r7[k] for k in ("bound", "achieved", "peak", "unit", "frac", "achieved_executed", "frac_executed",
+                                                          "traffic", "traffic_source", "kernel", "avg_launch_us", "share_of_kernel_time",
+                                                          "stack_tflops", "stack_tflops_executed", "kernel_ms_per_2steps", "kernels")}
+            result["chained"] = chained
             args.sublayers = "off"
             del w7
             torch.cuda.empty_cache()
@@ -613,6 +647,17 @@ def main():
             args.dtype, args.frames, args.steps, args.min_seconds = keep
             del w8
             torch.cuda.empty_cache()
+        # ... BASELINE configs[3] on ONE device (the 16-frame sequence a rank of an 8-GPU run would see as 4 frames) and configs[4]
+        # (SDXL + IP-Adapter, 8 frames, two passes on two streams): every BASELINE config has a driver-timed line
+        if not args.frames and not args.early and args.passes == "auto" and not args.separate_passes:
+            for key, wname in (("seq16_1gpu", "seq16"), ("ip", "ip")):
+                w9 = build_workload(wname, args, world, rank, device, torch, aid_amd)
+                t9 = time_workload(w9, args, world, device, torch, dist)
+                result["also"][key] = {"workload": w9["what"], "value": t9["value"], "unit": "frames/s", "ms_per_step": t9["ms_per_step"],
+                                       "repeats": t9["repeats"], "dtype": w9["dtype"], "frames": w9["n_total"], "early": w9["early"],
+                                       "passes": w9["passes"]}
+                del w9
+                torch.cuda.empty_cache()
         # ... and with the text keys / values projected in every call, like the reference
         if not args.no_text_kv_cache:
             aproc.TEXT_KV_CACHE = False

@@ -95,6 +95,67 @@ def test_world_size_2_gloo_sharded_equals_unsharded(n_frames):
         np.testing.assert_array_equal(full, out1[key])     # all_gather gives every rank the same tensor
 
 
+def _worker_w4(rank, world, port, n_frames, q):
+    """World-size 4: the rank program of a sharded run on the oracle — broadcast from rank 0 into NaN-filled buffers, local batch
+    [frame 0 ; owned ; frame N-1] with the rank's rows of the schedule, all_gather of the owned rows.  N = 16 takes its inputs from
+    the golden case `n16_d64_s_fused_outer` (the REFERENCE's 16-frame output is the expected result); N = 3 leaves rank 3 without a
+    frame of its own (it still runs the two end points and takes part in every collective)."""
+    import cases as C
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        if n_frames == 16:
+            case = next(c for c in C.TEXT_CASES if c.name == "n16_d64_s_fused_outer")
+            inp = C.text_inputs(case)
+            heads = case.heads
+            x0 = torch.from_numpy(inp["x"])
+            coef0 = torch.from_numpy(O.beta_coefs(16, 50, 50))
+        else:
+            g = torch.Generator().manual_seed(11)
+            heads = 2
+            x0 = torch.randn(n_frames, 6, 16, generator=g)
+            inp = {k: (torch.randn(16, 16, generator=g) / 4).numpy() for k in ("wq", "wk", "wv", "wo")}
+            inp["bo"] = torch.zeros(16).numpy()
+            coef0 = torch.linspace(0, 1, n_frames)
+        # non-source ranks start from NaN: whatever they compute with came through the broadcast
+        cond = dict(x=x0.clone() if rank == 0 else torch.full_like(x0, float("nan")),
+                    coef=coef0.clone() if rank == 0 else torch.full_like(coef0, float("nan")))
+        adist.broadcast_conditioning(cond, src=0)
+        shard = adist.frame_shard(n_frames, world, rank)
+        xl = adist.shard_rows(cond["x"], shard).numpy()
+        cl = adist.shard_rows(cond["coef"], shard).numpy()
+        w = O.AttnWeights(inp["wq"], inp["wk"], inp["wv"], inp["wo"], inp["bo"], heads)
+        local = O.outer_attention(xl, None, w, cl, True)
+        full = adist.gather_owned(torch.from_numpy(local), shard)
+        q.put((rank, shard.n_owned, shard.n_local, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [16, 5, 3])
+def test_world_size_4_gloo_rank_program(n_frames):
+    import cases as C
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_w4, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owned = [r[1] for r in res]
+    assert sum(owned) == n_frames and all(r[2] <= max(owned) + 2 for r in res)
+    if n_frames == 3:
+        assert owned == [1, 1, 1, 0] and res[3][2] == 2            # rank 3 owns nothing and runs the two end points
+    for r in res[1:]:
+        np.testing.assert_array_equal(r[3], res[0][3])             # all_gather: the same sequence on every rank
+    assert res[0][3].shape[0] == n_frames and np.isfinite(res[0][3]).all()
+    if n_frames == 16:                                             # ... and it is the REFERENCE's 16-frame output
+        gold = C.load_fixture("text_goldens.npz")["n16_d64_s_fused_outer"]
+        np.testing.assert_allclose(res[0][3], gold, rtol=0, atol=2e-6)
+
+
 def test_gather_owned_single_process():
     sh = adist.frame_shard(5, 1, 0)
     t = torch.arange(5.0).reshape(5, 1)
