@@ -38,9 +38,14 @@ __device__ __forceinline__ f32x16 mfma32f(float a, float b, const f32x16& c) {
 //     `ds_read_b128` lane group, and over the 2 x 4 (row, quad) lanes of a `ds_write_b128` group: no conflicts either way.
 //   * the swapped product D[n][m] leaves four consecutive n of one row m in a lane: 16-byte stores where the options allow.
 // ------------------------------------------------------------------------------------------------
-constexpr int FBM = 128, FBN = 128, FBK = 16, FLD = FBK + 4;
+// Two tile sizes: 128 x 128 (wave tile 64 x 64) for launches with enough tiles to fill the device, 64 x 64 (wave tile 32 x 32) for
+// the small levels of the SD1.5 stack at batch 3 (m = 3072 / 768 / 192: 120 / 60 / 20 tiles of 128 x 128 on 256 CUs) — the fp32 matrix
+// instruction takes 64 cycles, so the smaller tile's doubled LDS traffic per MFMA costs nothing and four times the workgroups are in flight.
+constexpr int FBK = 16, FLD = FBK + 4;
 
+template <int FBM>
 __global__ __launch_bounds__(256) void aid_gemm_f32_kernel(const GemmGroup g) {
+    constexpr int FBN = FBM, WT = FBM / 2, NB = WT / 32, RS = FBM / 64;       // wave tile, 32-blocks per side, staging rows per thread
     __shared__ __attribute__((aligned(16))) float smem[2 * (FBM + FBN) * FLD];
     // ---- block -> (problem, batch, tile)
     int p = 0;
@@ -60,38 +65,43 @@ __global__ __launch_bounds__(256) void aid_gemm_f32_kernel(const GemmGroup g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * WT, wn = (wave & 1) * WT;
     // staging: thread -> (row = tid / 4 [+ 64], k quad = tid % 4); rows past the matrix are clamped (their products are never stored)
     const int srow = tid >> 2, sq = (tid & 3) * 4;
-    const float* a0 = A + (int64_t)min(m0 + srow, P.m - 1) * P.lda + sq;
-    const float* a1 = A + (int64_t)min(m0 + srow + 64, P.m - 1) * P.lda + sq;
-    const float* b0 = B + (int64_t)min(n0 + srow, P.n - 1) * P.ldb + sq;
-    const float* b1 = B + (int64_t)min(n0 + srow + 64, P.n - 1) * P.ldb + sq;
+    const float* ap[RS];
+    const float* bp[RS];
+#pragma unroll
+    for (int i = 0; i < RS; ++i) {
+        ap[i] = A + (int64_t)min(m0 + srow + 64 * i, P.m - 1) * P.lda + sq;
+        bp[i] = B + (int64_t)min(n0 + srow + 64 * i, P.n - 1) * P.ldb + sq;
+    }
 
-    f32x16 acc[2][2];                                      // [n block][m block]
+    f32x16 acc[NB][NB];                                    // [n block][m block]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[RS], rb[RS];
     auto load = [&](int k0) {                              // k is a multiple of 8 (aid_hip.h): a quad is inside the row or past it
         const bool in = k0 + sq < P.k;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        ra[0] = in ? *reinterpret_cast<const f32x4*>(a0 + k0) : z;
-        ra[1] = in ? *reinterpret_cast<const f32x4*>(a1 + k0) : z;
-        rb[0] = in ? *reinterpret_cast<const f32x4*>(b0 + k0) : z;
-        rb[1] = in ? *reinterpret_cast<const f32x4*>(b1 + k0) : z;
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            ra[i] = in ? *reinterpret_cast<const f32x4*>(ap[i] + k0) : z;
+            rb[i] = in ? *reinterpret_cast<const f32x4*>(bp[i] + k0) : z;
+        }
     };
     auto store = [&](int buf) {
         float* As = smem + buf * (FBM + FBN) * FLD;
         float* Bs = As + FBM * FLD;
-        *reinterpret_cast<f32x4*>(As + srow * FLD + sq) = ra[0];
-        *reinterpret_cast<f32x4*>(As + (srow + 64) * FLD + sq) = ra[1];
-        *reinterpret_cast<f32x4*>(Bs + srow * FLD + sq) = rb[0];
-        *reinterpret_cast<f32x4*>(Bs + (srow + 64) * FLD + sq) = rb[1];
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            *reinterpret_cast<f32x4*>(As + (srow + 64 * i) * FLD + sq) = ra[i];
+            *reinterpret_cast<f32x4*>(Bs + (srow + 64 * i) * FLD + sq) = rb[i];
+        }
     };
 
     const int nk = (P.k + FBK - 1) / FBK;
@@ -104,18 +114,18 @@ __global__ __launch_bounds__(256) void aid_gemm_f32_kernel(const GemmGroup g) {
         const float* Bs = As + FBM * FLD;
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {                   // two groups of 8 k per tile
-            f32x4 fa[2], fb[2];
+            f32x4 fa[NB], fb[NB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NB; ++i) {
                 fa[i] = *reinterpret_cast<const f32x4*>(As + (wm + 32 * i + l31) * FLD + 8 * kg + 4 * hi);
                 fb[i] = *reinterpret_cast<const f32x4*>(Bs + (wn + 32 * i + l31) * FLD + 8 * kg + 4 * hi);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NB; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)            // D[n][m]: lane (m = l31, hi) ends up with n = 8 g + 4 hi + e
+                    for (int j = 0; j < NB; ++j)           // D[n][m]: lane (m = l31, hi) ends up with n = 8 g + 4 hi + e
                         acc[i][j] = mfma32f(fb[i][e], fa[j][e], acc[i][j]);
         }
         if (t + 1 < nk) store((t + 1) & 1);
@@ -129,11 +139,11 @@ __global__ __launch_bounds__(256) void aid_gemm_f32_kernel(const GemmGroup g) {
     const bool vec = !P.trans_rows && !stats && P.n % 4 == 0 &&     // whole 16-byte groups of a row: one store each
                      (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NB; ++j) {
         const int m = m0 + wm + 32 * j + l31;
         if (m >= P.m) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int nb = n0 + wn + 32 * i + 8 * gq + 4 * hi;
@@ -172,15 +182,36 @@ __global__ __launch_bounds__(256) void aid_gemm_f32_kernel(const GemmGroup g) {
     }
 }
 
-hipError_t gemm_f32_launch(GemmGroup& g, hipStream_t stream) {
+static int f32_tiles(GemmGroup& g, int bm) {
     int tiles = 0;
     for (int i = 0; i < g.n_problems; ++i) {
         g.tile_start[i] = tiles;
-        tiles += ((g.p[i].m + FBM - 1) / FBM) * ((g.p[i].n + FBN - 1) / FBN) * g.p[i].batch;
+        tiles += ((g.p[i].m + bm - 1) / bm) * ((g.p[i].n + bm - 1) / bm) * g.p[i].batch;
     }
     for (int i = g.n_problems; i <= AID_GEMM_MAX_PROBLEMS; ++i) g.tile_start[i] = tiles;
+    return tiles;
+}
+
+hipError_t gemm_f32_launch(GemmGroup& g, hipStream_t stream) {
+    // big tiles only when there are enough of them to give every CU two (512 on MI355X); same arithmetic either way (the K order
+    // inside a tile does not depend on the tile size: results are bit-identical)
+    static PerDevice<int> ncu;
+    int* n = ncu.slot();
+    if (!n) return hipErrorInvalidDevice;
+    if (*n == 0) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return hipErrorInvalidDevice;
+        *n = pr.multiProcessorCount;
+    }
+    int tiles = f32_tiles(g, 128);
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(aid_gemm_f32_kernel, dim3(tiles), dim3(256), 0, stream, g);
+    if (tiles >= 2 * *n) {
+        hipLaunchKernelGGL(aid_gemm_f32_kernel<128>, dim3(tiles), dim3(256), 0, stream, g);
+    } else {
+        tiles = f32_tiles(g, 64);
+        hipLaunchKernelGGL(aid_gemm_f32_kernel<64>, dim3(tiles), dim3(256), 0, stream, g);
+    }
     return hipGetLastError();
 }
 

@@ -155,6 +155,7 @@ class AidDenoiseLoop:
         self.use_graphs = use_graphs
         self.combine = combine or self._cfg
         self._graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+        self.fallback_reason: Optional[str] = None        # set when a capture failed and the loop went eager
         from . import ops
         self._ws = ops.WorkspaceOwner()          # the captures' workspaces are dropped with this loop (and its graphs)
         self._warmed: set = set()
@@ -225,8 +226,25 @@ class AidDenoiseLoop:
             cur.wait_stream(cap)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with self._ws, torch.cuda.graph(g, stream=cap):
-                self._outs[which] = self._pass(which)
+            try:
+                with self._ws, torch.cuda.graph(g, stream=cap):
+                    self._outs[which] = self._pass(which)
+            except RuntimeError as e:
+                # a pass that cannot be captured (a collective of the end-point-exchange layout on a stack whose RCCL does not record
+                # into graphs, a foreign UNet that synchronises): the loop goes on eagerly, loudly (pipelines._PassGraphs does the same)
+                import warnings
+                self.use_graphs = False
+                self.fallback_reason = f"{type(e).__name__}: {e}"
+                self._graphs.clear()
+                self._outs.clear()
+                self._ws.release()
+                warnings.warn("hipGraph capture of a pass failed, the loop continues eagerly: " + self.fallback_reason, RuntimeWarning,
+                              stacklevel=3)
+                try:
+                    torch.cuda.synchronize()
+                except RuntimeError as e2:
+                    raise RuntimeError(f"device unusable after a failed stream capture ({self.fallback_reason})") from e2
+                return self._pass(which)
             self._graphs[which] = g
         g.replay()
         return self._outs[which]

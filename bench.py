@@ -400,7 +400,9 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
         ex = adist.EndpointExchange(n_total, world, rank)
         for p in unet.attn_processors.values():
             p.endpoint_exchange, p.endpoint_ctx = ex, end_ctx
-        args.no_graph = True                 # a collective per layer: eager launches
+        # a collective per self-attention layer: RCCL records broadcast / all_gather and the exchange's side-stream fork / join into a
+        # hipGraph on this ROCm (tools/dev/rccl_graph_capture.py, profiles/r06_rccl_graph_capture.txt), so the passes are captured like
+        # the other layouts'; a stack that cannot falls back to eager launches inside AidDenoiseLoop and says so (config.graph_fallback)
     loop = AidDenoiseLoop(unet, xs, cond, uncond, num_inference_steps=steps, warmup_ratio=args.warmup_ratio,
                           use_graphs=not args.no_graph, batched_cfg=batched, ctx_index=ctx_index,
                           concurrent_cfg=(passes == "streams"))
@@ -519,7 +521,8 @@ def main():
                         "contexts are loop-invariant (reference pipeline_interpolated_sd.py:1859-1867 passes the same prompt_embeds "
                         "each step and re-projects them 50 times); `also.sdxl_text_kv_per_call` times the per-call projection"
                         if not args.no_text_kv_cache else "projected in every cross-attention call (like the reference)"),
-            "coef": f"BetaPPF(alpha=beta={steps})", "hipgraph": not args.no_graph,
+            "coef": f"BetaPPF(alpha=beta={steps})", "hipgraph": bool(loop.use_graphs),
+            "graph_fallback": getattr(loop, "fallback_reason", None),
             # stated tolerance of this storage dtype: rel-L2 of the final latents of a 50-step run vs the fp64 oracle loop
             # (tests/test_hip_depth_and_pipelines.py E2E50_BOUND; measured values in profiles/r04_depth_parity.json) and of one call
             "parity_tolerance": parity_statement(wl["dtype"]),
