@@ -341,13 +341,20 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
         }
     };
     if (UPF) {
-#pragma unroll
+        // ONE copy of the tile body: the register sets rotate (2 x 16 moves per tile; the loads all landed before the fill's barrier, so
+        // the moves wait for nothing) — three inlined copies pushed the three-segment instantiation to 161 spilled SGPRs
+        static_assert(TX_UPF_TILES == 3, "rotation below is written for three register sets");
+#pragma unroll 1
         for (int i = 0; i < TX_UPF_TILES; ++i) {
             const int tt = t + 4 * i;
-            if (tt < t_end) {
-                u32x4 ow[4];
-                compute(qu[i], ow);
-                store_rows(ow, tt);
+            if (tt >= t_end) break;
+            u32x4 ow[4];
+            compute(qu[0], ow);
+            store_rows(ow, tt);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qu[0][j] = qu[1][j];
+                qu[1][j] = qu[2][j];
             }
         }
         return;
