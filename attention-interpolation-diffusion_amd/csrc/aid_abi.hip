@@ -80,12 +80,12 @@ const char* const g_tune_names[aid::TUNE_COUNT] = {"GEMM_VARIANT", "GEMM_PP", "G
 // ablations (kernels that skip work, "results are garbage") exist only in development builds (-DAID_ABLATIONS, tools/dev/Makefile ->
 // tools/dev/libaid_abl.so) and are addressed through the same table there.
 #ifdef AID_ABLATIONS
-const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1, 8, 1, 2, 64};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1, 8, 1, 1, 64};
 #else
 #ifdef AID_RS_VARIANTS
-const int g_tune_max[aid::TUNE_COUNT] = {31, 7, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 2, 64};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 7, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64};
 #else
-const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 2, 64};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64};
 #endif
 #endif
 struct TuneTable {

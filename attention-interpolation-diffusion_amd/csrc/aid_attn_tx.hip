@@ -39,7 +39,6 @@ struct AttnTxParams {
     int32_t tiles_per_chunk;            // 32-row tiles a workgroup works through (4 waves, round robin)
     int32_t na;                         // heavy workgroups per head (balance hint: frames [0, n_frames - n_plain) x chunks)
     float   c2;                         // softmax_scale * log2(e), or 1 when q is pre-scaled
-    int32_t upfront;                    // 1: the UPF instantiation (every Q tile of a wave requested before the fill)
 };
 
 __device__ __forceinline__ f32x16 tx_zero16() {
@@ -92,12 +91,7 @@ __device__ __forceinline__ float tx_dot2<f16>(uint32_t w, float acc) {
 #endif
 
 // NSEG = LDS regions: 1 for PLAIN launches, 3 for OUTER launches (whose frames run one to three segments each).
-// UPF (round 6) = every Q tile of the wave is requested UP FRONT, before the fill: the phase stamps of round 5 show a wave waiting a full
-// LOADED memory latency (~4 us) per tile with one tile of prefetch — 3 tiles = 3 latencies — while the rows it will need later could
-// have been in flight from the first instruction on.  TX_UPF_TILES tiles per wave, 16 registers each; no load is issued after the first
-// store, so the shared load / store counter never makes a tile wait for the previous tile's stores.
-constexpr int TX_UPF_TILES = 3;
-template <typename T, int NSEG, bool UPF>
+template <typename T, int NSEG>
 __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tx_smem[];
     typedef typename Vec<T>::v8 T8;
@@ -150,20 +144,14 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
         for (int j = 0; j < 4; ++j) q[j] = *reinterpret_cast<const T8*>(src + 16 * j);
     };
     T8 qf[4];
-    T8 qu[UPF ? TX_UPF_TILES : 1][4];
     int t = t0 + wave;
-    if (UPF) {
-#pragma unroll
-        for (int i = 0; i < TX_UPF_TILES; ++i)
-            if (t + 4 * i < t_end) load_q(qu[i], t + 4 * i);             // all of this wave's rows: in flight across the fill
-    }
 #if defined(AID_TX_ABL) && AID_TX_ABL == 4
     const bool tx_trace = blockIdx.x == gridDim.x / 2 && wave == 0;
     uint64_t tx_ts[40];
     int tx_n = 0;
     TX_STAMP(0);                                        // kernel entry
 #endif
-    if (!UPF && t < t_end) load_q(qf, t);               // in flight across the fill
+    if (t < t_end) load_q(qf, t);                       // in flight across the fill
 
     // ---- fill: every segment of this (frame, head), once per workgroup ------------------------------------------------------------
 #if !defined(AID_TX_ABL) || AID_TX_ABL != 1
@@ -209,10 +197,8 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
     }
 #endif
     __syncthreads();
-    if (!UPF) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qf[j]));  // the first tile's Q has landed (the fill waited on the same counter)
-    }
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(qf[j]));      // the first tile's Q has landed (the fill waited on the same counter)
 
     const int nkt = (Lk + 31) >> 5;                                  // score tiles that hold a valid key
     const float c2 = p.c2;
@@ -340,25 +326,6 @@ __global__ __launch_bounds__(256, 2) void aid_attn_tx_kernel(const AttnTxParams 
             for (int w = 0; w < 4; ++w) *reinterpret_cast<u32x4*>(dst + 16 * w) = ow[w];
         }
     };
-    if (UPF) {
-        // ONE copy of the tile body: the register sets rotate (2 x 16 moves per tile; the loads all landed before the fill's barrier, so
-        // the moves wait for nothing) — three inlined copies pushed the three-segment instantiation to 161 spilled SGPRs
-        static_assert(TX_UPF_TILES == 3, "rotation below is written for three register sets");
-#pragma unroll 1
-        for (int i = 0; i < TX_UPF_TILES; ++i) {
-            const int tt = t + 4 * i;
-            if (tt >= t_end) break;
-            u32x4 ow[4];
-            compute(qu[0], ow);
-            store_rows(ow, tt);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                qu[0][j] = qu[1][j];
-                qu[1][j] = qu[2][j];
-            }
-        }
-        return;
-    }
     for (; t < t_end; t += 4) {
         T8 qn[4];
         const bool more = t + 4 < t_end;
@@ -405,12 +372,10 @@ bool attn_tx_supported(const AidAttnArgs& a) {
 template <typename T>
 static hipError_t tx_launch(const AttnTxParams& p, hipStream_t stream) {
     const bool outer = p.a.mode != AID_MODE_PLAIN;            // INNER / OUTER: the three-region instantiation
-    const bool upf = p.upfront != 0;
     const size_t smem = (size_t)(outer ? 3 : 1) * TX_REGION;
-    const void* fn = outer ? (upf ? reinterpret_cast<const void*>(&aid_attn_tx_kernel<T, 3, true>) : reinterpret_cast<const void*>(&aid_attn_tx_kernel<T, 3, false>))
-                           : (upf ? reinterpret_cast<const void*>(&aid_attn_tx_kernel<T, 1, true>) : reinterpret_cast<const void*>(&aid_attn_tx_kernel<T, 1, false>));
-    static PerDevice<int> attr_set[2];
-    int* done = attr_set[upf ? 1 : 0].slot();
+    const void* fn = outer ? reinterpret_cast<const void*>(&aid_attn_tx_kernel<T, 3>) : reinterpret_cast<const void*>(&aid_attn_tx_kernel<T, 1>);
+    static PerDevice<int> attr_set;
+    int* done = attr_set.slot();
     if (!done) return hipErrorInvalidDevice;
     if (outer && !*done) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -429,8 +394,6 @@ hipError_t attn_tx_launch(const AidAttnArgs& a, hipStream_t stream) {
     const int ntiles = (a.s + 31) / 32;
     int tpw = tune(TUNE_ATTN_TX_TILES);                      // 32-row tiles per wave (development knob)
     if (tpw <= 0) tpw = ntiles >= 96 ? 5 : 3;                // measured best of 1 ... 16 on the SDXL launches (S = 4096 : 5, S = 1024 : 3; flat within 3 % from 2 to 5)
-    p.upfront = tune(TUNE_ATTN_TX) == 2 ? 0 : 1;             // ATTN_TX = 2: round 5's one-tile-ahead loop (A/B)
-    if (p.upfront && tpw > TX_UPF_TILES) tpw = TX_UPF_TILES;
     int tpc = 4 * tpw;
     if (tpc > ntiles) tpc = ntiles;
     p.tiles_per_chunk = tpc;

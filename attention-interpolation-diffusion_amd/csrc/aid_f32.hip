@@ -228,16 +228,24 @@ struct AttnF32Params {
 // key index of accumulator register r in lane half hi (the mfma32 result layout): the r-th key a lane holds
 __device__ __forceinline__ int key_of(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-template <int D>
-__global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p) {
+// TWO = the launch has frames that take two softmax passes (OUTER): only then is a second accumulator set (the weighted sum of the
+// passes) needed beside the running one — PLAIN / INNER launches normalise their single pass in place (d = 160: 80 registers less).
+template <int D, bool TWO>
+__global__ __launch_bounds__(256, (D == 40 ? (TWO ? 2 : 3) : D == 64 ? 2 : D == 80 ? (TWO ? 1 : 2) : 1)) void aid_attn_f32_kernel(const AttnF32Params p) {
     constexpr int DP = (D + 31) / 32 * 32, NDB = DP / 32;          // channels padded to whole 32-blocks of the PV product
     // LDS rows of D + 4 / 32 + 4 floats: (row stride / 4) is odd, so the 16 rows of a `ds_read_b128` lane group start at 16 distinct
     // multiples of four banks — every fragment read below is one conflict-free 16-byte read that feeds FOUR MFMAs (see the GEMM).
     constexpr int KLD = D + 4;                                     // K tile rows [32][D + 4]
     constexpr int VLD = FKT + 4;                                   // V^T tile rows [DP][36]
     static_assert((KLD / 4) % 2 == 1 && (VLD / 4) % 2 == 1 && D % 8 == 0, "conflict-free 16-byte fragment reads");
-    __shared__ __attribute__((aligned(16))) float Ks[FKT * KLD];
-    __shared__ __attribute__((aligned(16))) float Vs[DP * VLD];
+    // PF (d <= 80): the NEXT tile's global loads are in flight during the current tile's MFMAs (registers -> the other LDS buffer after
+    // the arithmetic, ONE barrier per tile); d = 160 has no registers for it and stages synchronously through one buffer
+    constexpr bool PF = D <= 80;
+    constexpr int NBUF = PF ? 2 : 1;
+    constexpr int KCH = FKT * (D / 4), VCH = DP * (FKT / 4);       // 16-byte chunks of a K / V^T tile
+    constexpr int NKC = (KCH + 255) / 256, NVC = (VCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float Ks_[NBUF * FKT * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs_[NBUF * DP * VLD];
     const AidAttnArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -280,38 +288,79 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
 
     // one softmax pass over up to two key segments; its normalised output is added to `res` with weight w
     auto pass = [&](const float* k1, const float* v1, const float* k2, const float* v2, float w) {
-        f32x16 o[NDB];
+        f32x16 otmp[NDB];
+        f32x16 (&o)[NDB] = TWO ? otmp : res;                        // one pass per frame: accumulate where the result lives
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
         float mrow = -INFINITY, lsum = 0.f;                         // running reference and this lane half's partial row sum
-        for (int seg = 0; seg < 2; ++seg) {
-            const float* kp = seg ? k2 : k1;
-            const float* vp = seg ? v2 : v1;
-            if (!kp) continue;
-            for (int t0 = 0; t0 < a.l; t0 += FKT) {
-                __syncthreads();                                   // the previous tile has been consumed by every wave
-                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                for (int i = tid; i < FKT * (D / 4); i += 256) {   // K tile [key][channel], 16 bytes at a time
-                    const int kk = i / (D / 4), c = (i - kk * (D / 4)) * 4;
-                    *reinterpret_cast<f32x4*>(Ks + kk * KLD + c) =
-                        (t0 + kk < a.l) ? *reinterpret_cast<const f32x4*>(kp + (int64_t)(t0 + kk) * a.ldk + h * D + c) : z4;
-                }
-                for (int i = tid; i < DP * (FKT / 4); i += 256) {  // V^T tile [channel][key]; keys past L and pad channels are zero
-                    const int c = i / (FKT / 4), kk = (i - c * (FKT / 4)) * 4;
-                    f32x4 v = z4;
-                    if (c < D && t0 + kk < a.l) {
-                        const float* src = vp + (int64_t)(h * D + c) * a.ldvt + t0 + kk;
-                        if (t0 + kk + 3 < a.l) v = *reinterpret_cast<const f32x4*>(src);   // (ldvt, t0 and kk are multiples of 4)
-                        else {
+        const int ntl = (a.l + FKT - 1) / FKT;                      // tiles per segment
+        const int nt = (k2 ? 2 : 1) * ntl;                          // (k1 is never null)
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 rk[NKC], rv[NVC];
+        // tile i of the pass -> registers (chunks past the tile / the keys / the channels: zero)
+        auto gload = [&](int i) {
+            const float* kp = i >= ntl ? k2 : k1;
+            const float* vp = i >= ntl ? v2 : v1;
+            const int t0 = (i >= ntl ? i - ntl : i) * FKT;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = (t0 + kk + e < a.l) ? src[e] : 0.f;
-                        }
+            for (int u = 0; u < NKC; ++u) {                         // K tile [key][channel], 16 bytes at a time
+                const int id = tid + 256 * u;
+                const int kk = id / (D / 4), c = (id - kk * (D / 4)) * 4;
+                rk[u] = (id < KCH && t0 + kk < a.l) ? *reinterpret_cast<const f32x4*>(kp + (int64_t)(t0 + kk) * a.ldk + h * D + c) : z4;
+            }
+#pragma unroll
+            for (int u = 0; u < NVC; ++u) {                         // V^T tile [channel][key]; keys past L and pad channels are zero
+                const int id = tid + 256 * u;
+                const int c = id / (FKT / 4), kk = (id - c * (FKT / 4)) * 4;
+                f32x4 v = z4;
+                if (id < VCH && c < D && t0 + kk < a.l) {
+                    const float* src = vp + (int64_t)(h * D + c) * a.ldvt + t0 + kk;
+                    if (t0 + kk + 3 < a.l) v = *reinterpret_cast<const f32x4*>(src);       // (ldvt, t0 and kk are multiples of 4)
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (t0 + kk + e < a.l) ? src[e] : 0.f;
                     }
-                    *reinterpret_cast<f32x4*>(Vs + c * VLD + kk) = v;
                 }
-                __syncthreads();
+                rv[u] = v;
+            }
+        };
+        auto lstore = [&](int buf) {
+            float* Kb = Ks_ + buf * FKT * KLD;
+            float* Vb = Vs_ + buf * DP * VLD;
+#pragma unroll
+            for (int u = 0; u < NKC; ++u) {
+                const int id = tid + 256 * u;
+                const int kk = id / (D / 4), c = (id - kk * (D / 4)) * 4;
+                if (KCH % 256 == 0 || id < KCH) *reinterpret_cast<f32x4*>(Kb + kk * KLD + c) = rk[u];
+            }
+#pragma unroll
+            for (int u = 0; u < NVC; ++u) {
+                const int id = tid + 256 * u;
+                const int c = id / (FKT / 4), kk = (id - c * (FKT / 4)) * 4;
+                if (VCH % 256 == 0 || id < VCH) *reinterpret_cast<f32x4*>(Vb + c * VLD + kk) = rv[u];
+            }
+        };
+        __syncthreads();                                            // the previous pass has been consumed by every wave
+        if (PF) {
+            gload(0);
+            lstore(0);
+            __syncthreads();
+        }
+        for (int it = 0; it < nt; ++it) {
+            {
+                const int t0 = (it >= ntl ? it - ntl : it) * FKT;
+                const float* Ks = Ks_ + (PF ? (it & 1) : 0) * FKT * KLD;
+                const float* Vs = Vs_ + (PF ? (it & 1) : 0) * DP * VLD;
+                if (PF) {
+                    if (it + 1 < nt) gload(it + 1);                 // in flight across this tile's arithmetic
+                } else {
+                    if (it) __syncthreads();                        // the previous tile has been consumed by every wave
+                    gload(it);
+                    lstore(0);
+                    __syncthreads();
+                }
                 // S^T = K Q'^T: lane (query l31, half hi) receives the scores of keys key_of(r, hi)
                 f32x16 sc;
 #pragma unroll
@@ -346,10 +395,12 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
                 lsum = lsum * alpha + ps;
                 // O^T = alpha O^T + V^T P^T: k-step r contracts keys key_of(r, 0) (lower lane half) and key_of(r, 1) (upper);
                 // registers 4 j .. 4 j + 3 of a lane are the four CONSECUTIVE keys 8 j + 4 hi + {0 .. 3}: one 16-byte read of the V^T row
+                if (__any(alpha != 1.f)) {                          // (most tiles leave every row's reference where it was)
 #pragma unroll
-                for (int d = 0; d < NDB; ++d)
+                    for (int d = 0; d < NDB; ++d)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -358,13 +409,17 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[d] = mfma32f(vf[e], sc[4 * j + e], o[d]);
                     }
+                if (PF) {
+                    if (it + 1 < nt) lstore((it + 1) & 1);          // that buffer was last read a barrier ago
+                    __syncthreads();
+                }
             }
         }
         const float inv = w / sum_halves(lsum);
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) res[d][r] = fmaf(o[d][r], inv, res[d][r]);
+            for (int r = 0; r < 16; ++r) res[d][r] = TWO ? fmaf(o[d][r], inv, res[d][r]) : o[d][r] * inv;
     };
 
     const float* k_own = K0 + (int64_t)own * a.k_fs;
@@ -416,7 +471,10 @@ __global__ __launch_bounds__(256) void aid_attn_f32_kernel(const AttnF32Params p
 template <int D>
 static hipError_t attn_f32_run(const AttnF32Params& p, hipStream_t stream) {
     const int nqb = (p.a.s + 127) / 128;
-    hipLaunchKernelGGL(aid_attn_f32_kernel<D>, dim3(nqb * p.a.heads * p.a.n_frames), dim3(256), 0, stream, p);
+    if (p.a.mode == AID_MODE_OUTER)
+        hipLaunchKernelGGL((aid_attn_f32_kernel<D, true>), dim3(nqb * p.a.heads * p.a.n_frames), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((aid_attn_f32_kernel<D, false>), dim3(nqb * p.a.heads * p.a.n_frames), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

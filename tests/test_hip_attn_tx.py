@@ -257,23 +257,3 @@ def test_processor_path(kind):
     y = proc(attn, x, encoder_hidden_states=ctx)
     assert "aid_attn_tx" in ops.last_attn_variant(), ops.last_attn_variant()
     assert torch.equal(y, proc(attn, x, encoder_hidden_states=ctx)) and rel_l2(to_np64(y), ref) < TOL[dtype]
-
-
-@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
-@pytest.mark.parametrize("mode,fused", [("plain", False), ("outer", True), ("outer", False), ("inner", True)])
-def test_rows_requested_up_front_give_the_bits_of_the_one_ahead_loop(dtype, mode, fused, tuning):
-    """Round 6: every Q tile of a wave is requested before the fill (aid_attn_tx_kernel<.., UPF = true>, the default) instead of one tile
-    ahead of the arithmetic (ATTN_TX = 2: round 5's loop).  Same arithmetic on the same tiles: the outputs are equal bit for bit, at
-    query counts that leave waves with 0, 1, 2 and 3 tiles."""
-    n, l, h = 5, 77, 3
-    for s in (1, 40, 130, 300, 385, 1024):
-        q, k, v = _inputs(n, n, s, l, h, dtype, seed=900 + s)
-        kc, vc = _compact(k, v)
-        coef = torch.tensor([0.0, 0.3, 1.0, -1.0, -1.0], device=DEV) if mode != "plain" else None
-        kw = dict(l=l, mode=mode, fused=fused, coef=coef, begin=0, end=2, n_plain=2 if mode != "plain" else 0)
-        o = ops.attn_fwd(q.to(DEV), kc, vc, h, **kw)
-        assert "aid_attn_tx" in ops.last_attn_variant()
-        tuning("ATTN_TX", 2)
-        o_old = ops.attn_fwd(q.to(DEV), kc, vc, h, **kw)
-        tuning("ATTN_TX", -1)
-        assert torch.equal(o, o_old), (s, mode, fused)
