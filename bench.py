@@ -157,7 +157,7 @@ def parity_statement(dt):
     run matters; bf16, the dtype BASELINE names for SDXL, pays 8x the rounding step)."""
     stated = {"f16": (1e-3, 2.35e-3), "bf16": (8e-3, 2.2e-2), "f32": (1e-5, 1e-5)}[dt]     # (= 1.3 x the largest measured value)
     out = {"per_call_rel_l2": stated[0], "latents_50_steps_rel_l2": stated[1]}
-    for name in ("r05_depth_parity.json", "r04_depth_parity.json"):
+    for name in ("r06_depth_parity.json", "r05_depth_parity.json", "r04_depth_parity.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Collect rocprofv3 PMC counters per launch of every aid_* kernel of the bench workloads -> profiles/r05_pmc.json.
+"""Collect rocprofv3 PMC counters per launch of every aid_* kernel of the bench workloads -> profiles/r06_pmc.json.
 
 Procedure (MI355X_MICROARCH.md, HBM / PMC-slot sections): every counter group is its OWN rocprofv3 pass with
 --kernel-trace only (never combined with sys / hip / memory-copy tracing), over
@@ -121,7 +121,7 @@ def main():
         return
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     wls = sys.argv[sys.argv.index("--workloads") + 1].split(",") if "--workloads" in sys.argv else ["sdxl", "sd15"]
-    out = argv[0] if argv else os.path.join(ROOT, "profiles", "r05_pmc.json")
+    out = argv[0] if argv else os.path.join(ROOT, "profiles", "r06_pmc.json")
     res = {"_comment": __doc__.split("usage")[0].strip(), "models": {}}
     for wl in wls:
         merged = collections.defaultdict(dict)

@@ -1,9 +1,9 @@
-# Re-create the round's measurement set on the GPU box (run from the repo root under gpurun); results land in gpurun_out/r05/
-# and are copied to profiles/r05_* after review:  bench lines, rocprofv3 kernel-trace summaries of the SAME commands, the PMC
+# Re-create the round's measurement set on the GPU box (run from the repo root under gpurun); results land in gpurun_out/r06/
+# and are copied to profiles/r06_* after review:  bench lines, rocprofv3 kernel-trace summaries of the SAME commands, the PMC
 # collection (tools/pmc_collect.py), the per-launch breakdown of both stacks, the projection microbenchmark, the attention
 # A/B table of the knobs that decide the variants, the sublayer modes.
 set -x
-R=gpurun_out/r05; mkdir -p $R
+R=gpurun_out/r06; mkdir -p $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $R/bench_default.json 2> $R/bench_default.err
 timeout 400 python bench.py --workload ip --steps 20 --warmup 5 > $R/bench_ip.json 2> $R/bench_ip.err
 timeout 400 python bench.py --workload seq16 --steps 20 --warmup 5 --no-cpu-baseline > $R/bench_seq16.json 2> $R/bench_seq16.err
