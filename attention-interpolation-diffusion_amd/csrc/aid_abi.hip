@@ -82,7 +82,7 @@ const char* const g_tune_names[aid::TUNE_COUNT] = {"GEMM_VARIANT", "GEMM_PP", "G
 #ifdef AID_ABLATIONS
 const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1, 8, 1, 1, 64};
 #else
-#ifdef AID_RS_VARIANTS
+#if defined(AID_RS_VARIANTS) || defined(AID_PPX_ORDERS)
 const int g_tune_max[aid::TUNE_COUNT] = {31, 7, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64};
 #else
 const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64};

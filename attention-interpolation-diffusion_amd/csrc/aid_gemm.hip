@@ -948,6 +948,7 @@ struct PingPongX : PingPong<T> {
     using PP::ra; using PP::rb; using PP::avo; using PP::bvo;
     f32x16 accx;
     int xoff, xx, xvo;
+    int kmul = 128;             // bytes per K tile in the DMA's scalar offset (development order 4 freezes it at 0: every request an L2 hit)
 #ifdef AID_ABLATIONS
     int abl_ = 0;               // development builds: 4 = epilogue without the global stores, 8 = without the staging pass
 #endif
@@ -976,12 +977,19 @@ struct PingPongX : PingPong<T> {
         for (int j = 0; j < 2; ++j) {
             char* dst = smem + (t & 1) * STGX + (IS_A ? 0 : 2 * HALF) + H * HALF + wave * 2048 + j * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_A ? ra : rb, (__attribute__((address_space(3))) void*)dst, 16,
-                                                     IS_A ? avo[H * 2 + j] : bvo[H * 2 + j], (kb + t) * 128, 0, 0);
+                                                     IS_A ? avo[H * 2 + j] : bvo[H * 2 + j], (kb + t) * kmul, 0, 0);
         }
+    }
+    __device__ __forceinline__ void xdma_one(const int Q, const int j, int t, int kb) {     // piece j (0 / 1) of half-tile Q
+        const bool IS_A = Q >= 2;
+        const int H = Q & 1;
+        char* dst = smem + (t & 1) * STGX + (IS_A ? 0 : 2 * HALF) + H * HALF + wave * 2048 + j * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_A ? ra : rb, (__attribute__((address_space(3))) void*)dst, 16,
+                                                 IS_A ? avo[H * 2 + j] : bvo[H * 2 + j], (kb + t) * kmul, 0, 0);
     }
     __device__ __forceinline__ void dma_strip(int t, int kb) {  // waves 0 - 3 only
         char* dst = smem + (t & 1) * STGX + 4 * HALF + wave * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, xvo, (kb + t) * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)dst, 16, xvo, (kb + t) * kmul, 0, 0);
     }
     __device__ __forceinline__ void read_x(T8 (&fx)[4], const char* st) {
 #pragma unroll
@@ -1000,10 +1008,14 @@ struct PingPongX : PingPong<T> {
     // TR: the problem wants C transposed per frame (GemmDesc.trans_rows): the MFMAs are issued the other way round
     // (D rows = m, columns = n), so a lane ends up with four consecutive ROWS of one output column and the staged tile
     // can be written n-major with the same 8-byte stores.
-    template <int WR, bool TR>
+    // ORD (development build -DAID_PPX_ORDERS, GEMM_PP = 4 .. 6; same arithmetic, same results): where a read slot issues its LDS-DMA
+    // requests — 0 behind the fragment reads (round 3, the product), 1 in front of them, 2 one request per four reads; 3 = order 0 with
+    // s_setprio 1 on the MFMA slots
+    template <int WR, bool TR, int ORD>
     __device__ __forceinline__ void mac_x(int kb, int ke) {
         const int nk = ke - kb;
         const bool xw = wave < 4;
+        if (ORD == 4) kmul = 0;             // (timing only, results are garbage: the K loop with every operand request served by the L2)
         xdma_half(0, 0, kb); xdma_half(1, 0, kb); xdma_half(2, 0, kb); xdma_half(3, 0, kb);
         if (xw) dma_strip(0, kb);
         if (nk > 1) {
@@ -1018,26 +1030,49 @@ struct PingPongX : PingPong<T> {
         auto body = [&](int kt, auto more1_t, auto more2_t) __attribute__((always_inline)) {
             constexpr bool M1 = decltype(more1_t)::value, M2 = decltype(more2_t)::value;   // tile kt + 1 / kt + 2 exists
             const char* st = smem + (kt & 1) * STGX;
-            this->read_b(fb, st);
-            this->read_a(fa, st, 0);
-            if (M1) {
-                xdma_half(2, kt + 1, kb); xdma_half(3, kt + 1, kb);
+            auto rdb = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fb[j][ks] = *reinterpret_cast<const T8*>(st + boff[0] + j * HALF + (((2 * ks) ^ bx[0]) << 4));
+            };
+            auto rda = [&](int e, int h) __attribute__((always_inline)) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[e][ks] = *reinterpret_cast<const T8*>(st + h * HALF + aoff[e] + (((2 * ks) ^ ax[e]) << 4));
+            };
+            auto pinb = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+            if (ORD == 1 && M1) { xdma_half(2, kt + 1, kb); xdma_half(3, kt + 1, kb); if (xw) dma_strip(kt + 1, kb); pinb(); }
+            if (ORD == 2 && M1) {
+                xdma_one(2, 0, kt + 1, kb); pinb(); rdb(0); pinb(); xdma_one(2, 1, kt + 1, kb); pinb(); rdb(1); pinb();
+                xdma_one(3, 0, kt + 1, kb); pinb(); rda(0, 0); pinb(); xdma_one(3, 1, kt + 1, kb); pinb(); rda(1, 0); pinb();
                 if (xw) dma_strip(kt + 1, kb);
+            } else {
+                this->read_b(fb, st);
+                this->read_a(fa, st, 0);
+            }
+            if (M1) {
+                if (ORD == 0 || ORD >= 3) { xdma_half(2, kt + 1, kb); xdma_half(3, kt + 1, kb); if (xw) dma_strip(kt + 1, kb); }
                 wait_rd<8>(xw);
             } else {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
             PP::slot();
+            if (ORD == 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ks = i >> 2, in = (i >> 1) & 1, e = i & 1;
                 acc[in][e] = TR ? mfma32(fa[e][ks], fb[in][ks], acc[in][e]) : mfma32(fb[in][ks], fa[e][ks], acc[in][e]);
             }
+            if (ORD == 3) __builtin_amdgcn_s_setprio(0);
             PP::slot();
-            this->read_a(fa, st, 1);
-            read_x(fx, st);
+            if (ORD == 1 && M2) { xdma_half(0, kt + 2, kb); xdma_half(1, kt + 2, kb); pinb(); }
+            if (ORD == 2 && M2) {
+                xdma_one(0, 0, kt + 2, kb); pinb(); rda(0, 1); pinb(); xdma_one(0, 1, kt + 2, kb); pinb(); rda(1, 1); pinb();
+                xdma_one(1, 0, kt + 2, kb); pinb(); read_x(fx, st); pinb(); xdma_one(1, 1, kt + 2, kb);
+            } else {
+                this->read_a(fa, st, 1);
+                read_x(fx, st);
+            }
             if (M2) {
-                xdma_half(0, kt + 2, kb); xdma_half(1, kt + 2, kb);
+                if (ORD == 0 || ORD >= 3) { xdma_half(0, kt + 2, kb); xdma_half(1, kt + 2, kb); }
                 wait_rd<6>(xw);
             } else if (M1) {
                 wait_rd<2>(xw);
@@ -1045,6 +1080,7 @@ struct PingPongX : PingPong<T> {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
             PP::slot();
+            if (ORD == 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ks = i >> 2, in = (i >> 1) & 1, e = i & 1;
@@ -1052,6 +1088,7 @@ struct PingPongX : PingPong<T> {
                 if ((i & 3) == 3)                                               // the strip's block: this wave's own B fragment
                     accx = TR ? mfma32(fx[ks], fb[WR][ks], accx) : mfma32(fb[WR][ks], fx[ks], accx);
             }
+            if (ORD == 3) __builtin_amdgcn_s_setprio(0);
             PP::slot();
         };
         const std::true_type Y{};
@@ -1067,6 +1104,7 @@ struct PingPongX : PingPong<T> {
     // Whole tile: four copies of (K loop + epilogue) — fb[WR] must be a compile-time register choice and the operand order
     // a compile-time choice; the epilogue sits INSIDE each copy so that no accumulator crosses a control-flow merge (with a
     // common epilogue behind the four loops hipcc spilled 80 accumulator registers at the join).
+    template <int ORD>
     __device__ __forceinline__ void run_tile(const GemmDesc& P, T* C, int batch, int m0, int n0
 #ifdef AID_ABLATIONS
                                              , int abl = 0
@@ -1076,15 +1114,15 @@ struct PingPongX : PingPong<T> {
         const T* R = P.residual ? reinterpret_cast<const T*>(P.residual) + (int64_t)batch * P.stride_c : nullptr;
         const float* st = P.ln_stats ? P.ln_stats + 2 * (int64_t)batch * P.stride_stats : nullptr;
         if (P.trans_rows) {
-            if (wr == 0) { mac_x<0, true>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
-            else         { mac_x<1, true>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
+            if (wr == 0) { mac_x<0, true, ORD>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
+            else         { mac_x<1, true, ORD>(0, nk); store_tile_t(P, reinterpret_cast<T*>(P.c), m0, n0, P.ln_stats); }
         } else {
 #ifdef AID_ABLATIONS
             // (timing ablations of development builds — 1 = no epilogue, 2 = no K loop; one call site per instantiation: a second
             //  `mac_x<1, false>` call elsewhere fails to instantiate in hipcc's host pass)
             abl_ = abl;
-            if (wr == 0) { if (!(abl & 2)) mac_x<0, false>(0, nk); if (!(abl & 1)) store_tile(P, C, m0, n0, R, st); }
-            else         { if (!(abl & 2)) mac_x<1, false>(0, nk); if (!(abl & 1)) store_tile(P, C, m0, n0, R, st); }
+            if (wr == 0) { if (!(abl & 2)) mac_x<0, false, ORD>(0, nk); if (!(abl & 1)) store_tile(P, C, m0, n0, R, st); }
+            else         { if (!(abl & 2)) mac_x<1, false, ORD>(0, nk); if (!(abl & 1)) store_tile(P, C, m0, n0, R, st); }
             if (abl & 1) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -1093,8 +1131,8 @@ struct PingPongX : PingPong<T> {
                 asm volatile("" ::"v"(accx));
             }
 #else
-            if (wr == 0) { mac_x<0, false>(0, nk); store_tile(P, C, m0, n0, R, st); }
-            else         { mac_x<1, false>(0, nk); store_tile(P, C, m0, n0, R, st); }
+            if (wr == 0) { mac_x<0, false, ORD>(0, nk); store_tile(P, C, m0, n0, R, st); }
+            else         { mac_x<1, false, ORD>(0, nk); store_tile(P, C, m0, n0, R, st); }
 #endif
         }
     }
@@ -1352,7 +1390,7 @@ struct PingPongX : PingPong<T> {
 static_assert((288 * 32) % 512 == 0 && (256 * 36) % 512 == 0, "C rows divide over the threads");
 static_assert(Engine<bf16, 128, 128, 64, 4, 2, 4>::SMEM <= PingPongX<bf16>::SMEMX, "side tiles use the big tile's LDS");
 
-template <typename T>
+template <typename T, int ORD = 0>
 __global__ __launch_bounds__(512) void aid_gemm_nt_ppx_kernel(const GemmGroup g, const GemmSide sd
 #ifdef AID_ABLATIONS
                                                               , const int abl      // development builds only: timing ablations
@@ -1395,9 +1433,9 @@ __global__ __launch_bounds__(512) void aid_gemm_nt_ppx_kernel(const GemmGroup g,
     e.set_tile(P, A, B, tc.m0, tc.n0);
     e.zero_acc();
 #ifdef AID_ABLATIONS
-    e.run_tile(P, C, tc.batch, tc.m0, tc.n0, abl);
+    e.template run_tile<ORD>(P, C, tc.batch, tc.m0, tc.n0, abl);
 #else
-    e.run_tile(P, C, tc.batch, tc.m0, tc.n0);
+    e.template run_tile<ORD>(P, C, tc.batch, tc.m0, tc.n0);
 #endif
 }
 
@@ -1604,7 +1642,21 @@ static hipError_t launch_ppx(GemmGroup& g, hipStream_t stream, const GemmSide& s
     const int abl = tune(TUNE_GEMM_PP) >= 8 ? tune(TUNE_GEMM_PP) - 8 : 0;
     hipLaunchKernelGGL(aid_gemm_nt_ppx_kernel<T>, dim3(sd.pad_tiles + tiles), dim3(512), PingPongX<T>::SMEMX, stream, g, sd, abl);
 #else
+#ifdef AID_PPX_ORDERS
+    // development build (tools/dev/Makefile, libaid_ppxord.so): the read-slot orders of mac_x side by side, GEMM_PP = 4 / 5 / 6
+    const int ord = tune(TUNE_GEMM_PP) - 3;
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PingPongX<T>::SMEMX);
+        hipLaunchKernelGGL(kern, dim3(sd.pad_tiles + tiles), dim3(512), PingPongX<T>::SMEMX, stream, g, sd);
+    };
+    if (ord == 1)      go(aid_gemm_nt_ppx_kernel<T, 1>);
+    else if (ord == 2) go(aid_gemm_nt_ppx_kernel<T, 2>);
+    else if (ord == 3) go(aid_gemm_nt_ppx_kernel<T, 3>);
+    else if (ord == 4) go(aid_gemm_nt_ppx_kernel<T, 4>);      // timing ablation: garbage results
+    else               go(aid_gemm_nt_ppx_kernel<T, 0>);
+#else
     hipLaunchKernelGGL(aid_gemm_nt_ppx_kernel<T>, dim3(sd.pad_tiles + tiles), dim3(512), PingPongX<T>::SMEMX, stream, g, sd);
+#endif
 #endif
     return hipGetLastError();
 }
