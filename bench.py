@@ -400,6 +400,8 @@ def build_workload(name, args, world, rank, device, torch, aid_amd):
         ex = adist.EndpointExchange(n_total, world, rank)
         for p in unet.attn_processors.values():
             p.endpoint_exchange, p.endpoint_ctx = ex, end_ctx
+        if os.environ.get("AID_BENCH_ONE_DEVICE") == "1":
+            args.no_graph = True             # development mode: gloo collectives run on the host and cannot be captured
         # a collective per self-attention layer: RCCL records broadcast / all_gather and the exchange's side-stream fork / join into a
         # hipGraph on this ROCm (tools/dev/rccl_graph_capture.py, profiles/r06_rccl_graph_capture.txt), so the passes are captured like
         # the other layouts'; a stack that cannot falls back to eager launches inside AidDenoiseLoop and says so (config.graph_fallback)
