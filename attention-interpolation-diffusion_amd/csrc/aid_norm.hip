@@ -81,42 +81,57 @@ __global__ __launch_bounds__(256) void aid_layernorm_kernel(const T* __restrict_
 // aid_ln_stats_kernel reads the activations once and writes (mean, rstd) per row — the normalised tensor is never
 // materialised (the separate LayerNorm kernel writes and the projection re-reads [rows, c]); aid_ln_fold_kernel prepares
 // the weight side once per (weights, gamma, beta).  Same statistics arithmetic as aid_layernorm_kernel above.
+// LN_RPW rows per wave, every row's loads issued before the first reduction: a wave's life is one memory latency, and with one row per
+// wave (round 2 - 5) the 14336-row launches of the SDXL stack were two rounds of 32 waves per CU, each a latency long (12 us for 36.7 MB).
+constexpr int LN_RPW = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void aid_ln_stats_kernel(const T* __restrict__ x, float* __restrict__ stats, int64_t rows,
                                                            int c, float eps) {
     typedef typename Vec<T>::v8 T8;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
+    if (row0 >= rows) return;
     const int nch = c >> 3;
-    const T* xr = x + row * c;
-    f32x8 v[LN_MAX_CHUNKS];
-    float s = 0.f;
+    T8 raw[LN_RPW][LN_MAX_CHUNKS];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
-            v[i] = up8<T>(*reinterpret_cast<const T8*>(xr + ch * 8));
+    for (int r = 0; r < LN_RPW; ++r) {
+        const T* xr = x + (row0 + r < rows ? row0 + r : rows - 1) * c;       // (rows past the end: a valid row, its result is dropped)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[i][e];
+        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+            const int ch = lane + 64 * i;
+            raw[r][i] = ch < nch ? *reinterpret_cast<const T8*>(xr + ch * 8) : zero8<T>();
         }
     }
-    const float mean = wave_sum(s) / (float)c;
-    float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
-        if (lane + 64 * i < nch) {
+    for (int r = 0; r < LN_RPW; ++r) {
+        // the arithmetic of one row, in the order of aid_layernorm_kernel (same sums, same bits as the one-row-per-wave version)
+        float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = v[i][e] - mean;
-                q = fmaf(d, d, q);
+        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+            if (lane + 64 * i < nch) {
+                const f32x8 v = up8<T>(raw[r][i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[e];
             }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
-    if (lane == 0) {
-        stats[2 * row] = mean;
-        stats[2 * row + 1] = rstd;
+        const float mean = wave_sum(s) / (float)c;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+            if (lane + 64 * i < nch) {
+                const f32x8 v = up8<T>(raw[r][i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[e] - mean;
+                    q = fmaf(d, d, q);
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+        if (lane == 0 && row0 + r < rows) {
+            stats[2 * (row0 + r)] = mean;
+            stats[2 * (row0 + r) + 1] = rstd;
+        }
     }
 }
 
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(256) void aid_ln_fold_kernel(const T* __restrict__ 
 
 hipError_t ln_stats_launch(const void* x, float* stats, int64_t rows, int c, float eps, int dtype, hipStream_t stream) {
     if (rows <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((rows + 3) / 4));
+    const dim3 grid((unsigned)((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)));
     if (dtype == AID_DTYPE_F16)
         hipLaunchKernelGGL(aid_ln_stats_kernel<f16>, grid, dim3(256), 0, stream, (const f16*)x, stats, rows, c, eps);
     else
