@@ -24,8 +24,8 @@ __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
 
 template <int ABL>
-__global__ __launch_bounds__(256) void k(const bf16* __restrict__ A, const bf16* __restrict__ B, float* out, int nk, int lda, int ldb,
-                                         int tiles_n, int reps) {
+__global__ __launch_bounds__(256) void k(const bf16* __restrict__ A, const bf16* __restrict__ B, float* out, long long* cyc, int nk, int lda,
+                                         int ldb, int tiles_n, int reps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void k(const bf16* __restrict__ A, const bf16*
         if (w < 4) fa[set][w] = *reinterpret_cast<const bf16x8*>(st + aoff[w] + (((2 * ks) ^ ax[w]) << 4));
         else       fb[set][w - 4] = *reinterpret_cast<const bf16x8*>(st + boff[w - 4] + (((2 * ks) ^ ax[w - 4]) << 4));
     };
+    const long long c0 = clock64();
     for (int rep = 0; rep < reps; ++rep) {
         // prologue: tile 0 -> parity 0
 #pragma unroll
@@ -79,6 +80,11 @@ __global__ __launch_bounds__(256) void k(const bf16* __restrict__ A, const bf16*
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < 8; ++w) rd(0, 0, 0, w);
+        if (ABL & 2) {                                                         // no reads in the loop: both register sets hold real operands
+#pragma unroll
+            for (int w = 0; w < 8; ++w) rd(1, 0, 1, w);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         for (int kt = 0; kt < nk; ++kt) {
             const int p = kt & 1;
             const int ktn = kt + 1 < nk ? kt + 1 : 0;                          // (the last tile re-requests tile 0: nobody reads it)
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(256) void k(const bf16* __restrict__ A, const bf16*
         }
         __syncthreads();
     }
+    if (tid == 0) cyc[blockIdx.x] = clock64() - c0;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void k(const bf16* __restrict__ A, const bf16*
 }
 
 template <int ABL>
-void run(const char* tag, const bf16* A, const bf16* B, float* out, int m, int n, int kdim) {
+void run(const char* tag, const bf16* A, const bf16* B, float* out, long long* cyc, int m, int n, int kdim) {
     const int tiles_m = m / 256, tiles_n = n / 256, nk = kdim / 64, reps = 8;
     const int grid = tiles_m * tiles_n;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STG);
@@ -131,33 +138,47 @@ void run(const char* tag, const bf16* A, const bf16* B, float* out, int m, int n
     float best = 1e9f;
     for (int it = 0; it < 6; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k<ABL>, dim3(grid), dim3(256), 2 * STG, 0, A, B, out, nk, kdim, kdim, tiles_n, reps);
+        hipLaunchKernelGGL(k<ABL>, dim3(grid), dim3(256), 2 * STG, 0, A, B, out, cyc, nk, kdim, kdim, tiles_n, reps);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (it && ms < best) best = ms;
     }
+    std::vector<long long> hc(grid);
+    hipMemcpy(hc.data(), cyc, grid * sizeof(long long), hipMemcpyDeviceToHost);
+    double cs = 0; for (auto c : hc) cs += (double)c;
+    const double cyc_tile = cs / grid / (reps * nk);
     const double rounds = (double)((grid + 255) / 256);
     const double us_tile = best * 1e3 / (reps * nk * rounds);
     const double tf = 2.0 * 256 * 256 * 64 * grid * reps * nk / (best * 1e-3) / 1e12;
-    printf("%-34s grid %4d  %8.1f us / launch  %6.3f us per 256x256x64 K tile and CU round  %7.0f TF/s (whole launch incl. prologues)\n", tag, grid,
-           best * 1e3 / reps, us_tile, tf);
+    printf("%-28s %7.1f us per pass of 20 K tiles  %6.3f us = %5.0f shader cycles per 256x256x64 K tile (2048 = pure MFMA issue)  eff. clock %4.2f GHz  %5.0f TF/s\n",
+           tag, best * 1e3 / reps, us_tile, cyc_tile, cyc_tile / us_tile * 1e-3, tf);
 }
 
 int main() {
     const int m = 14336, n = 1280, kdim = 1280;
     bf16 *A, *B; float* out;
     hipMalloc(&A, (size_t)m * kdim * 2); hipMalloc(&B, (size_t)n * kdim * 2); hipMalloc(&out, 4096 * 256 * 4);
+    long long* cyc; hipMalloc(&cyc, 4096 * sizeof(long long));
     std::vector<unsigned short> h((size_t)m * kdim);
-    for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (unsigned short)((i * 2654435761u) >> 22 & 0x1ff);   // bf16 near 0.01 .. 0.03: random mantissas
+    unsigned long long x = 88172645463325252ull;                              // xorshift: random sign, mantissa and three exponent bits (|v| in [0.06, 16))
+    for (size_t i = 0; i < h.size(); ++i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        h[i] = (unsigned short)(((x >> 20) & 0x83ff) | (((x >> 40) & 7) + 0x7b) << 7);
+    }
     hipMemcpy(A, h.data(), (size_t)m * kdim * 2, hipMemcpyHostToDevice);
     hipMemcpy(B, h.data(), (size_t)n * kdim * 2, hipMemcpyHostToDevice);
     printf("four waves, one per SIMD, 256 x 256 x 64 tiles; 13056 x 1280 x 1280 = 255 tiles = ONE round of one tile per CU, 20 K tiles, 8 repetitions inside the launch\n");
     printf("(pure MFMA time of a 256 x 256 x 64 K tile: 2048 cycles per SIMD = 0.98 us at 2.09 GHz, 0.85 us at 2.4 GHz)\n");
     const int m1 = 13056;
-    run<0>("full loop", A, B, out, m1, n, kdim);
-    run<1>("no DMA requests", A, B, out, m1, n, kdim);
-    run<2>("no fragment reads", A, B, out, m1, n, kdim);
-    run<3>("MFMAs + barrier only", A, B, out, m1, n, kdim);
+    run<0>("full loop", A, B, out, cyc, m1, n, kdim);
+    run<1>("no DMA requests", A, B, out, cyc, m1, n, kdim);
+    run<2>("no fragment reads", A, B, out, cyc, m1, n, kdim);
+    run<3>("MFMAs + barrier only", A, B, out, cyc, m1, n, kdim);
+    hipMemset(A, 0, (size_t)m * kdim * 2);
+    hipMemset(B, 0, (size_t)n * kdim * 2);
+    printf("the same with ALL-ZERO operands (the clock the power budget allows depends on the data):\n");
+    run<0>("full loop, zeros", A, B, out, cyc, m1, n, kdim);
+    run<3>("MFMAs + barrier only, zeros", A, B, out, cyc, m1, n, kdim);
     return 0;
 }
