@@ -21,7 +21,7 @@ python tools/kbench_attn_ab.py "ATTN_V2=-1" "ATTN_V2=0" --rounds 5 --iters 6 --s
 python tools/kbench_attn_ab.py "ATTN_TX=0" "ATTN_TX=-1" --rounds 5 --iters 6 --shapes sdxl --only x77 > $R/kbench_attn_tx.txt 2>/dev/null
 python tools/gemm_ab.py "GEMM_TRI=0,GEMM_PP=0" "GEMM_TRI=0,GEMM_PP=1" "GEMM_TRI=-1,GEMM_PP=1" --rounds 5 --iters 10 --torch > $R/gemm_ab.txt 2>/dev/null
 python tools/gemm_ab.py "GEMM_RS=0" "GEMM_RS=-1" "GEMM_RS=1" --short --rounds 5 --iters 10 > $R/gemm_rs_ab.txt 2>/dev/null
-for u in mfma_cadence store_bw valu_rate barrier_cost wave_simd head_stride_copy; do
+for u in mfma_cadence store_bw valu_rate barrier_cost wave_simd head_stride_copy mfma_ceiling gemm_w4_model; do
   [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/$u tools/ubench/$u.hip
   ./tools/ubench/$u > $R/ubench_$u.txt 2>&1
 done
