@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(NW * 64) void aid_attn_kernel(const AttnKParams p) 
                     T8 v = *reinterpret_cast<const T8*>(stg + row * RBY + ((SWZ ? cc ^ ((row >> 1) & 7) : cc) << 4));
                     const int q = q0 + row;
                     const int vo = (min(q, a.s - 1) * a.ldo + cc * 8) * 2;
-                    if (q < a.s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, so, 0);
+                    if (q < a.s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, so, AID_ST_AUX);
                 }
             }
         }

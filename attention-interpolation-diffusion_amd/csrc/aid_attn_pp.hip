@@ -650,7 +650,7 @@ __global__ __launch_bounds__(512) void aid_attn_pp_kernel(const AttnPPParams p) 
                 const int q = q0 + row;
                 const int vo = (min(q, a.s - 1) * a.ldo + cc * 8) * 2;
                 if (a.accumulate) v = cvt8<T>(up8<T>(v) + up8<T>(__builtin_bit_cast(T8, __builtin_amdgcn_raw_buffer_load_b128(ro, vo, so, 0))));
-                if (q < a.s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, so, 0);
+                if (q < a.s) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, vo, so, AID_ST_AUX);
             }
         }
     };

@@ -3,6 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Cache policy of the big output stores (buffer-store aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1).  0 = plain write-back stores (the
+// product); development builds (tools/dev/Makefile, libaid_st<aux>.so) try the others: a kernel boundary is a release of everything
+// the kernel left dirty in the L2s, and write-through stores leave nothing dirty (profiles/r06_notes.md).
+#ifndef AID_ST_AUX
+#define AID_ST_AUX 0
+#endif
+
 namespace aid {
 
 typedef _Float16 f16;

@@ -345,7 +345,7 @@ __device__ __forceinline__ void store_rows_fast(const T* Cs, T* C, const T* R, i
             T8 o = v[i];
             if (R) o = cvt8<T>(up8<T>(v[i]) + up8<T>(r[i]));
             if (r0 + RPP * (g0 + i) < rows_valid)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, voff, (g0 + i) * pass, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, voff, (g0 + i) * pass, AID_ST_AUX);
         }
     }
 }
