@@ -74,18 +74,18 @@ struct ProfScope {          // records an event pair around one launch when prof
 
 // ---- tuning knobs (aid_kernels.hpp: enum Tune) -----------------------------------------------------
 const char* const g_tune_names[aid::TUNE_COUNT] = {"GEMM_VARIANT", "GEMM_PP", "GEMM_TRI", "ATTN_NW", "ATTN_QB", "ATTN_PIPE",
-                                                   "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2", "CU_SHARE", "GEMM_RS", "ATTN_TX", "ATTN_TX_TILES"};
+                                                   "ATTN_RES", "ATTN_RES_CHUNKS", "ATTN_ORDER", "ATTN_V2", "CU_SHARE", "GEMM_RS", "ATTN_TX", "ATTN_TX_TILES", "GEMM_LS"};
 // Largest value a knob accepts.  Every accepted value selects between kernels / launch shapes that compute THE SAME RESULT (the parity
 // suite runs under each of them); values beyond the range are refused by aid_set_tuning and ignored in the environment.  The timing
 // ablations (kernels that skip work, "results are garbage") exist only in development builds (-DAID_ABLATIONS, tools/dev/Makefile ->
 // tools/dev/libaid_abl.so) and are addressed through the same table there.
 #ifdef AID_ABLATIONS
-const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1, 8, 1, 1, 64};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 15, 1, 8, 2, 1, 1, 1000, 1, 1, 8, 1, 1, 64, 1};
 #else
 #if defined(AID_RS_VARIANTS) || defined(AID_PPX_ORDERS)
-const int g_tune_max[aid::TUNE_COUNT] = {31, 7, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 7, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64, 1};
 #else
-const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64};
+const int g_tune_max[aid::TUNE_COUNT] = {31, 3, 1, 8, 2, 1, 1, 64, 1, 1, 8, 1, 1, 64, 1};
 #endif
 #endif
 struct TuneTable {

@@ -1837,7 +1837,22 @@ static hipError_t launch_gemm_sel(GemmGroup& g, hipStream_t stream, const char**
     if (pp) plan_pp(g, ncu, g.p[0].k / 64);             // g.tile_start back in 256 x 256 units
     if (variant) *variant = !pp ? "lockstep128" : pl.n_small ? "pingpong256+tail128" : "pingpong256";
     if (pp) return launch_pp<T>(g, stream, pl, sd);
-    return launch_pipe<T, 128, 128, 64, 2, 2, 4>(g, stream);       // 8 waves, 64 x 32 wave tiles, 2 workgroups / CU
+    // 8 waves, 64 x 32 wave tiles.  The ring: a K tile's loads are in flight for ~0.75 us whatever the launch (HBM / L2 latency), so a
+    // workgroup that is alone on its CU with ONE tile ahead is latency-bound (0.75 us per K tile against 0.24 us of MFMAs).
+    // Measured (profiles/r06_gemm_lockstep_rings.txt): a K tile step costs 0.5 - 0.65 us with one tile ahead and ~0.5 with three ahead —
+    // what bounds it is the CU's own fill rate (32 KB per step at 64 B / clk), not the latency; the deeper ring pays 8 - 12 % only
+    // where a launch leaves at most one workgroup per CU and has a long K loop (C = 1280 levels of SD1.5, text contexts of SDXL), and
+    // costs 10 - 15 % wherever two workgroups share a CU (its 128 KB ring keeps the second one out).  Same bits either way.
+    // (32-wide K tiles — four stages in 64 KB, or three in 48 KB for three workgroups per CU — lost everywhere: same file.)
+    int ls = tune(TUNE_GEMM_LS);
+    if (ls < 0) {
+        const int t128 = plan_tiles(g, 128, 128);
+        int nk_min = 1 << 30;
+        for (int i = 0; i < g.n_problems; ++i) nk_min = g.p[i].k / 64 < nk_min ? g.p[i].k / 64 : nk_min;
+        ls = (t128 >= 64 && t128 <= num_cu() && nk_min >= 16) ? 1 : 0;
+    }
+    if (ls == 1) { if (variant) *variant = "lockstep128x4"; return launch_pipe<T, 128, 128, 64, 4, 2, 4>(g, stream); }
+    return launch_pipe<T, 128, 128, 64, 2, 2, 4>(g, stream);       // 2 workgroups / CU
 }
 
 hipError_t gemm_group_launch(GemmGroup& g, int dtype, hipStream_t stream, const char** variant, int cu_share) {

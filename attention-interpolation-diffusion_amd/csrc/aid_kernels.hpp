@@ -65,6 +65,8 @@ enum Tune {
                                 // default: wherever the shape allows AND the activation has enough row tiles to fill the device
     TUNE_ATTN_TX,               // text-key kernel (aid_attn_tx.hip: d = 64, <= 96 keys per segment, PLAIN / INNER / OUTER): 0 = never; default: wherever supported
     TUNE_ATTN_TX_TILES,         // > 0: 32-row tiles per wave of that kernel (sets the workgroups per (frame, head))
+    TUNE_GEMM_LS,               // ring of the lock-step engine: 0 = 2 stages of 64 k, 2 workgroups / CU (rounds 1 - 5); 1 = 4 stages of 64 k,
+                                // 1 workgroup / CU; default: 1 for launches of at most one workgroup per CU with >= 16 K tiles (aid_gemm.hip)
     TUNE_COUNT
 };
 int tune(int id);

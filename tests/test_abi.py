@@ -190,7 +190,7 @@ def test_integration_doc_stub_matches_the_header():
 
 # ---- no setting may change results ----------------------------------------------------
 KNOB_MAX = {"GEMM_VARIANT": 31, "GEMM_PP": 3, "GEMM_TRI": 1, "ATTN_NW": 8, "ATTN_QB": 2, "ATTN_PIPE": 1, "ATTN_RES": 1,
-            "ATTN_RES_CHUNKS": 64, "ATTN_ORDER": 1, "ATTN_V2": 1, "CU_SHARE": 8, "GEMM_RS": 1, "ATTN_TX": 1, "ATTN_TX_TILES": 64}
+            "ATTN_RES_CHUNKS": 64, "ATTN_ORDER": 1, "ATTN_V2": 1, "CU_SHARE": 8, "GEMM_RS": 1, "ATTN_TX": 1, "ATTN_TX_TILES": 64, "GEMM_LS": 1}
 
 
 def test_tuning_knobs_refuse_values_outside_their_range():

@@ -60,7 +60,8 @@ def test_gemm_nt_vs_fp64(dtype, mnk):
                                             ((57344, 320, 320), "lockstep128", -1),           # short K loop (row-stationary engine off)
                                             ((57344, 320, 320), "rowstat320", -1),            # ... and what the launch gets by default
                                             ((57344, 640, 640), "rowstat640", -1),            # SDXL level 1 out projection
-                                            ((1000, 1280, 2048), "lockstep128", -1)])         # too few tiles
+                                            ((1000, 1280, 2048), "lockstep128x4", -1),       # too few tiles for the big engines: alone on its CU, long K loop -> deep ring
+                                            ((448, 1280, 768), "lockstep128", -1)])           # ... short K loop: the two-stage ring
 def test_gemm_engine_selection_and_parity(dtype, mnk, engine, tri, tuning):
     """The k % 64 == 0 engines against fp64 on sampled rows (every row panel edge included), and the cost model
     sends each shape to the engine the stack measurements favour (profiles/r01_gemm_variants.txt, profiles/r03_gemm_notes.txt)."""
@@ -1090,3 +1091,26 @@ def test_gemm_transposed_per_frame_output(dtype, tri, frames, keys, c, k, tuning
         xn = O.layer_norm(to_np64(e), to_np64(gamma), to_np64(beta), 1e-5).reshape(frames, keys, k)
         refl = np.einsum("ck,flk->fcl", to_np64(wv), xn)
         assert rel_l2(to_np64(vl), refl) < 2 * TOL_GEMM[dtype], (name, ops.last_gemm_variant())
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=ids_dt)
+@pytest.mark.parametrize("mnk", [(1792, 1280, 1280), (7168, 640, 640), (1078, 320, 768), (1000, 1272, 2048), (130, 72, 64)])
+def test_lockstep_ring_depths_give_the_same_bits(dtype, mnk, tuning):
+    """GEMM_LS: the rings of the lock-step engine (2 stages, 2 workgroups / CU; 4 stages, 1 workgroup / CU) change how far ahead the
+    loads run, not the order of the sums: bit-identical outputs, ragged m / n edges and a one-tile K loop included."""
+    m, n, k = mnk
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(dtype).to(DEV)
+    b = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype).to(DEV)
+    bias = torch.randn(n, generator=g).to(dtype).to(DEV)
+    tuning("GEMM_VARIANT", 7)
+    tuning("GEMM_RS", 0)
+    outs, names = [], []
+    for ls in (0, 1):
+        tuning("GEMM_LS", ls)
+        outs.append(ops.linear(a, b, bias).clone())
+        names.append(ops.last_gemm_variant())
+    assert names == ["lockstep128", "lockstep128x4"]
+    ref = to_np64(a) @ to_np64(b).T + to_np64(bias)
+    assert rel_l2(to_np64(outs[0]), ref) < TOL_GEMM[dtype]
+    assert torch.equal(outs[0], outs[1])

@@ -37,6 +37,14 @@ if "--short" in sys.argv:        # the short-K levels (row-stationary engine, GE
 if "--shards" in sys.argv:       # the C = 1280 projections at the local batches of a sharded 16-frame sequence (2 x 4 / 6 / 9 frames x 1024 rows)
     SHAPES = [(f"sdxl L2 {nm} {f}f ({m},1280,1280)", [(m, 1280, 1280)] * c) for f in (4, 6, 9) for m in (2 * f * 1024,)
               for nm, c in (("qkv 3x", 3), ("out", 1))]
+if "--ls" in sys.argv:          # launches of the lock-step engine (GEMM_LS): one pass (7 frames) of the SD1.5 stack, f16 in the bench (--f16)
+    SHAPES = [("sd15 L0 out (28672,320,320)", [(28672, 320, 320)]), ("sd15 L1 out (7168,640,640)", [(7168, 640, 640)]),
+              ("sd15 L1 qkv 3x(7168,640,640)", [(7168, 640, 640)] * 3),
+              ("sd15 L2 out (1792,1280,1280)", [(1792, 1280, 1280)]), ("sd15 L2 qkv 3x(1792,1280,1280)", [(1792, 1280, 1280)] * 3),
+              ("sd15 mid out (448,1280,1280)", [(448, 1280, 1280)]), ("sd15 mid qkv 3x(448,1280,1280)", [(448, 1280, 1280)] * 3),
+              ("sd15 L0 text k+v 2x(1078,320,768)", [(1078, 320, 768)] * 2), ("sd15 L2 text k+v 2x(1078,1280,768)", [(1078, 1280, 768)] * 2),
+              ("sd15 L1 out cfg-batched (14336,640,640)", [(14336, 640, 640)]), ("sd15 L2 out cfg-batched (3584,1280,1280)", [(3584, 1280, 1280)]),
+              ("sdxl L2 text k+v 2x(1078,1280,2048)", [(1078, 1280, 2048)] * 2)]
 if "--sd15" in sys.argv:
     SHAPES = [("sd15 L0 qkv 3x(57344,320,320)", [(57344, 320, 320)] * 3), ("sd15 L0 out", [(57344, 320, 320)]),
               ("sd15 L1 qkv 3x(14336,640,640)", [(14336, 640, 640)] * 3), ("sd15 L1 out", [(14336, 640, 640)]),
@@ -53,7 +61,7 @@ def timed(fn):
 
 
 def apply(v):
-    for name in ("GEMM_VARIANT", "GEMM_PP", "GEMM_TRI", "GEMM_RS", "CU_SHARE"):
+    for name in ("GEMM_VARIANT", "GEMM_PP", "GEMM_TRI", "GEMM_RS", "CU_SHARE", "GEMM_LS"):
         ops.set_tuning(name, v.get(name, -1))
 
 
@@ -78,7 +86,9 @@ for label, probs in SHAPES:
                 run()
                 torch.cuda.synchronize()
                 err = ((outs[-1].float() - ref).norm() / ref.norm()).item()
-                names[i] = (ops.last_gemm_variant(), err)
+                if i == 0:
+                    first = outs[-1].clone()
+                names[i] = (ops.last_gemm_variant() + ("" if torch.equal(first, outs[-1]) else " BITS-DIFFER"), err)
                 run()
             res[i].append(timed(run))
     for i, v in enumerate(variants):
