@@ -2,9 +2,10 @@
 // Dense v_mfma_f32_32x32x16 issue, nothing else: every CU runs four waves (one per SIMD), each wave 64 back-to-back MFMAs per loop
 // trip on 16 rotating accumulators (no dependency stall: 32.0 cycles per MFMA and SIMD, tools/ubench/mfma_cadence.hip), operands
 // held in registers.  The instruction stream is the same for every data set; what changes is the CLOCK the power budget allows:
-//   zeros            the chip stays near its nominal clock (~2.1 GHz under this load): ~2.0 PFLOP/s
-//   random operands  (N(0, 1) samples rounded to bf16 / f16 — the benchmark's synthetic activations) the clock drops until the power fits: the POWER-LIMITED dense rate, the ceiling a real GEMM or
-//                    attention kernel of this library meets first (MI355X_MICROARCH.md "DVFS give-back").
+//   zeros            the chip stays near its top clock (2.3 - 2.4 GHz under this load): 2.43 - 2.49 PFLOP/s, the data-sheet figure
+//   random operands  (N(0, 1) samples rounded to bf16 / f16 — the benchmark's synthetic activations) the clock drops until the power fits
+//                    (1.6 - 1.7 GHz): 1.66 - 1.82 PFLOP/s, the POWER-LIMITED dense rate — the ceiling a real GEMM or attention kernel of
+//                    this library meets first (MI355X_MICROARCH.md "DVFS give-back"; profiles/r06_notes.md section 6).
 // Prints one JSON line; bench.py runs this binary (when present) and reports the rate next to the nominal 2.5 PFLOP/s peak.
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_ceiling mfma_ceiling.hip
 #include <hip/hip_runtime.h>
