@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for w in sdxl sd15; do
   rm -rf /tmp/prof_$w
   timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-also --min-seconds 0 $([ $w = sd15 ] && echo --passes serial) > $GRAFT_REPO_ROOT/$R/${w}_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$R/${w}_rocprof.err
-  db=$(find /tmp/prof_$w -name '*.db' | head -1)
+  db=$(ls -S $(find /tmp/prof_$w -name '*.db') | head -1)      # the bench's own database, not the one of the mfma_ceiling subprocess it starts
   python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $db $GRAFT_REPO_ROOT/$R/${w}_kernel_stats.txt > /dev/null
 done
 cd $GRAFT_REPO_ROOT
